@@ -1,0 +1,230 @@
+"""CPU oracle for the FSW_conv / FSW_embedding forward hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the reference's algorithm.  It is imported only by
+tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg, and only as the checker.  The
+product path (fsw_gnn_amd/) never imports it and has no CPU fallback.
+
+Parity pin: every function here is checked in tests/test_oracle_vs_golden.py against golden vectors
+captured from the reference's own CPU path (/root/reference/fsw_embedding.py, fsw_conv.py run
+unmodified in the build container by oracle/make_goldens.py; fixtures under tests/golden/).
+
+Each function cites the reference lines (paths relative to /root/reference/) it restates.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------------
+# adjacency construction                                                     fsw_conv.py:384-447
+# --------------------------------------------------------------------------------------------------
+def coalesce_edge_index(edge_index, num_vertices, self_loop_weight=0.0, edge_weighting="unit",
+                        edge_values=None, dtype=np.float64):
+    """edge_index [2,E] (row 0 = sender, row 1 = recipient) -> CSR of adj[recipient, sender].
+
+    fsw_conv.py:387      inds = edge_index.flip(0)  (row = recipient, col = sender)
+    fsw_conv.py:388      unit values
+    fsw_conv.py:390-395  optional self loops of weight self_loop_weight
+    fsw_conv.py:397-398  coalesce(): duplicates summed, entries sorted by (recipient, sender)
+    fsw_conv.py:400-409  in-degrees; 'gcn' weighting divides by sqrt(deg_i) * sqrt(deg_j)
+    Returns rowptr[int64 n+1], col[int64 nnz], w[dtype nnz], in_degrees[dtype n].
+    """
+    edge_index = np.asarray(edge_index)
+    src = edge_index[0].astype(np.int64)
+    dst = edge_index[1].astype(np.int64)
+    vals = np.ones(src.shape[0], dtype=dtype) if edge_values is None else np.asarray(edge_values, dtype=dtype)
+    if self_loop_weight > 0:
+        loops = np.arange(num_vertices, dtype=np.int64)
+        src = np.concatenate([src, loops])
+        dst = np.concatenate([dst, loops])
+        vals = np.concatenate([vals, np.full(num_vertices, self_loop_weight, dtype=dtype)])
+    key = dst * np.int64(num_vertices) + src
+    order = np.argsort(key, kind="stable")
+    key = key[order]
+    vals = vals[order]
+    if key.size:
+        first = np.concatenate([[True], key[1:] != key[:-1]])
+    else:
+        first = np.zeros(0, dtype=bool)
+    seg = np.cumsum(first) - 1
+    ukey = key[first]
+    w = np.zeros(ukey.shape[0], dtype=dtype)
+    np.add.at(w, seg, vals)
+    row = ukey // num_vertices
+    col = ukey % num_vertices
+    rowptr = np.zeros(num_vertices + 1, dtype=np.int64)
+    np.add.at(rowptr, row + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    in_deg = np.zeros(num_vertices, dtype=dtype)
+    np.add.at(in_deg, row, w)
+    if edge_weighting == "gcn":
+        ds = np.sqrt(in_deg)
+        w = w / ds[row] / ds[col]
+    elif edge_weighting != "unit":
+        raise RuntimeError("Invalid weighting method passed in argument <edge_weighting>")
+    return rowptr, col, w, in_deg
+
+
+def csr_from_coo(rows, cols, vals, num_rows):
+    """Coalesced COO (sorted by (row, col)) -> CSR.  Used for FSW_embedding.forward(W=sparse)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    rowptr = np.zeros(num_rows + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr), np.asarray(cols, dtype=np.int64), np.asarray(vals)
+
+
+# --------------------------------------------------------------------------------------------------
+# embedding core                                                       fsw_embedding.py:778-1112
+# --------------------------------------------------------------------------------------------------
+def fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh=1.0, dtype=np.float64,
+                  chunk_elems=1 << 23, return_mass=False):
+    """out[r, k] = (1+xi_k) * sum_t Delta_t * p_(t)  for every CSR row r and slice k.
+
+    fsw_embedding.py:778-784    mass m_r = sum of the row's weights
+    fsw_embedding.py:787        pad deficit max(tau - m_r, 0)
+    fsw_embedding.py:790-821    if ANY row is deficient every row gets one extra element x = 0 carrying
+                                its deficit (zero for non-deficient rows)
+    fsw_embedding.py:817,823-829 normalise by max(m_r, tau)
+    fsw_embedding.py:909-913    projection Xp = X . projVecs^T
+    fsw_embedding.py:917-932,1016-1025  per-slice ascending sort of the neighbourhood, weights follow
+    fsw_embedding.py:1031-1032  inclusive cumulative weights c_t (the segmented cumsum)
+    fsw_embedding.py:1047-1075  Delta_t = 2 w_t sinc(xi w_t) cos(pi xi (2 c_t - w_t)),
+                                sinc(z) = sin(pi z)/(pi z)
+    fsw_embedding.py:1084-1109  out = (1+xi) * sum_t Delta_t p_(t)
+    """
+    X = np.asarray(X, dtype=dtype)
+    V = np.asarray(projVecs, dtype=dtype)
+    xi = np.asarray(freqs, dtype=dtype)
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    w = np.asarray(w, dtype=dtype)
+    tau = np.dtype(dtype).type(total_mass_pad_thresh)
+    nrows = rowptr.shape[0] - 1
+    S = V.shape[0]
+    deg = np.diff(rowptr)
+
+    mass = np.zeros(nrows, dtype=dtype)
+    np.add.at(mass, np.repeat(np.arange(nrows), deg), w)
+    deficit = np.maximum(tau - mass, 0)
+    any_deficit = bool((deficit > 0).any())
+    denom = np.maximum(mass, tau) if any_deficit else mass
+
+    Xp = X @ V.T                                                   # [n, S]
+    out = np.zeros((nrows, S), dtype=dtype)
+
+    for D in np.unique(deg):
+        rows = np.nonzero(deg == D)[0]
+        Dp = int(D) + (1 if any_deficit else 0)
+        if Dp == 0:
+            continue
+        step = max(1, chunk_elems // max(1, Dp * S))
+        for a in range(0, rows.shape[0], step):
+            rr = rows[a:a + step]
+            R = rr.shape[0]
+            idx = rowptr[rr][:, None] + np.arange(D)[None, :]      # [R, D]
+            keys = np.zeros((R, Dp, S), dtype=dtype)
+            wts = np.zeros((R, Dp), dtype=dtype)
+            if D > 0:
+                keys[:, :D, :] = Xp[col[idx]]
+                wts[:, :D] = w[idx]
+            if any_deficit:
+                wts[:, D] = deficit[rr]                            # pad element at x = 0
+            wts = wts / denom[rr][:, None]
+            order = np.argsort(keys, axis=1, kind="stable")
+            ks = np.take_along_axis(keys, order, axis=1)
+            ws = np.take_along_axis(np.broadcast_to(wts[:, :, None], keys.shape), order, axis=1)
+            c = np.cumsum(ws, axis=1)
+            delta = 2 * ws * np.sinc(xi[None, None, :] * ws) * np.cos(np.pi * xi[None, None, :] * (2 * c - ws))
+            out[rr] = (1 + xi)[None, :] * np.sum(delta * ks, axis=1)
+    if return_mass:
+        return out, mass
+    return out
+
+
+def total_mass_encode(out, mass, function="identity", method="plain", scale=1.0):
+    """Prepend the total-mass column.                               fsw_embedding.py:853-884
+
+    'identity' f(m)=m; 'sqrt' f(m)=2m/(sqrt(m+1)+1); 'log' f(m)=log1p(m)        (:857-865)
+    'plain'  -> [f*scale, emb]; 'homog' -> [f*scale*mean|emb|, emb];
+    'homog_alt' -> [part1(f*scale)*mean|emb|, part2(f*scale)*emb]                (:874-882, 1136-1144)
+    """
+    m = mass[:, None]
+    if function == "identity":
+        tm = m.copy()
+    elif function == "sqrt":
+        tm = 2 * (m / (np.sqrt(m + 1) + 1))
+    elif function == "log":
+        tm = np.log1p(m)
+    else:
+        raise RuntimeError("bad total_mass_encoding_function")
+    tm = tm * scale
+    if method == "plain":
+        return np.concatenate([tm, out], axis=-1)
+    norm = np.mean(np.abs(out), axis=-1, keepdims=True)
+    if method == "homog":
+        return np.concatenate([tm * norm, out], axis=-1)
+    if method == "homog_alt":
+        p1 = np.where(tm <= 1, tm * (2 - tm), 1)
+        p2 = np.where(tm <= 1, tm * tm, 2 * tm - 1)
+        return np.concatenate([p1 * norm, p2 * out], axis=-1)
+    raise RuntimeError("bad total_mass_encoding_method")
+
+
+def fsw_embedding_forward(X, rowptr, col, w, projVecs, freqs, bias=None, encode_total_mass=False,
+                          total_mass_encoding_function="identity", total_mass_encoding_method="plain",
+                          total_mass_encoding_scale=1.0, total_mass_pad_thresh=1.0, dtype=np.float64):
+    """FSW_embedding.forward in graph mode on a CSR adjacency.    fsw_embedding.py:587-890"""
+    emb, mass = fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh, dtype, return_mass=True)
+    if encode_total_mass:
+        emb = total_mass_encode(emb, mass, total_mass_encoding_function, total_mass_encoding_method,
+                                np.dtype(dtype).type(total_mass_encoding_scale))
+    if bias is not None:
+        emb = emb + np.asarray(bias, dtype=dtype)                  # fsw_embedding.py:886-888
+    return emb
+
+
+def point_cloud_forward(X, W, projVecs, freqs, total_mass_pad_thresh=1.0, dtype=np.float64):
+    """Non-graph mode: X [b, n, d], W [b, n] (or None = unit) -> [b, S].  fsw_embedding.py:704-728, 983-1004
+
+    The dense branch of the reference computes diff(2 c sinc(2 xi c)); by the sum-to-product identity
+    this equals the sparse branch's 2 w sinc(xi w) cos(pi xi (2c - w)) used here.
+    """
+    X = np.asarray(X, dtype=dtype)
+    b, n, d = X.shape
+    Wd = np.ones((b, n), dtype=dtype) if W is None else np.asarray(W, dtype=dtype)
+    rowptr = np.arange(b + 1, dtype=np.int64) * n
+    col = np.arange(b * n, dtype=np.int64)
+    return fsw_embed_csr(X.reshape(b * n, d), rowptr, col, Wd.reshape(-1), projVecs, freqs,
+                         total_mass_pad_thresh, dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# FSW_conv tail                                                             fsw_conv.py:357-369
+# --------------------------------------------------------------------------------------------------
+def conv_tail(emb, vertex_features, message_weight_vs_self=1.0, concat_self=True, linear_weight=None,
+              linear_bias=None, negative_slope=0.2):
+    """cat(mw * emb, x) -> one Linear + LeakyReLU layer (the default mlp_layers=1 MLP)."""
+    h = np.concatenate([message_weight_vs_self * emb, vertex_features], axis=-1) if concat_self else emb
+    if linear_weight is None:
+        return h
+    y = h @ np.asarray(linear_weight, dtype=h.dtype).T
+    if linear_bias is not None:
+        y = y + np.asarray(linear_bias, dtype=h.dtype)
+    return np.where(y >= 0, y, negative_slope * y)
+
+
+# --------------------------------------------------------------------------------------------------
+# segmented cumulative sum                                     fsw_embedding.py:3016-3027
+# --------------------------------------------------------------------------------------------------
+def segcumsum(values, segment_ids):
+    """Inclusive scan of values restarted wherever consecutive segment_ids differ (segcumsum_slow)."""
+    values = np.asarray(values)
+    ids = np.asarray(segment_ids)
+    n = values.shape[0]
+    if n == 0:
+        return values.copy()
+    start = np.concatenate([[True], ids[1:] != ids[:-1]])
+    out = np.empty_like(values)
+    # sequential definition, vectorised per segment so rounding matches a left-to-right sum
+    bounds = np.nonzero(start)[0].tolist() + [n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        out[a:b] = np.cumsum(values[a:b])
+    return out
