@@ -1,0 +1,256 @@
+"""FSW_conv / FSW_readout: host-side mirror of the reference's PyG layers (reference fsw_conv.py:54-517).
+
+Same constructor surface (including the `config` override dictionary, reference fsw_conv.py:185-205), same
+parameter names (`fsw_embed.*`, `mlp.*`, `dim_reduct`, `bn_final.*`, `size_coeff`) and the same
+forward(vertex_features, edge_index, edge_features=None) contract.  The adjacency is built as a CSR on the
+GPU (graph.py) instead of a coalesced torch.sparse_coo tensor, the neighbourhood embedding is written by the
+HIP kernels straight into the left columns of the concat buffer, and the MLP / BatchNorm tail stays stock
+torch.nn as in the reference (fsw_conv.py:357-369).
+
+When torch_geometric is importable the classes derive from MessagePassing and register themselves with
+graphgym under 'fsw_conv' / 'fsw_readout' like the reference (fsw_conv.py:54, 451); otherwise they are plain
+nn.Modules (the reference never calls propagate(): message/aggregate/update are empty stubs, :374-381).
+"""
+import inspect
+
+import numpy as np
+import torch
+
+from .fsw_embedding import FSW_embedding
+from .graph import build_csr
+
+try:  # optional dependency, exactly the names the reference imports (fsw_conv.py:4-9)
+    from torch_geometric.nn import MessagePassing as _Base
+    from torch_geometric.graphgym.register import register_layer, register_pooling
+    _HAVE_PYG = True
+except Exception:  # pragma: no cover - torch_geometric is absent in the build image
+    _Base = torch.nn.Module
+    _HAVE_PYG = False
+
+    def register_layer(name):
+        return lambda cls: cls
+
+    def register_pooling(name):
+        return lambda cls: cls
+
+
+@register_layer('fsw_conv')
+class FSW_conv(_Base):
+    def __init__(self,
+                 in_channels, out_channels, edgefeat_dim=0,
+                 embed_dim=None, learnable_embedding=True,
+                 encode_vertex_degrees=True, vertex_degree_encoding_function='identity',
+                 vertex_degree_encoding_scale=1.0, learnable_vertex_degree_encoding_scale=False, homog_degree_encoding=False,
+                 vertex_degree_pad_thresh=1.0,
+                 concat_self=True, message_weight_vs_self=1.0,
+                 bias=True,
+                 mlp_layers=1, mlp_hidden_dim=None,
+                 mlp_activation_final=torch.nn.LeakyReLU(negative_slope=0.2),
+                 mlp_activation_hidden=torch.nn.LeakyReLU(negative_slope=0.2),
+                 mlp_init=None,
+                 batchNorm_final=False, batchNorm_hidden=False,
+                 dropout_final=0, dropout_hidden=0,
+                 self_loop_weight=0, edge_weighting='unit',
+                 device=None, dtype=torch.float32,
+                 config=None):
+        if _HAVE_PYG:
+            super().__init__(aggr=None)
+        else:
+            super().__init__()
+        config = dict(config) if config is not None else {}
+        arg_names = {p.name for p in inspect.signature(FSW_conv.__init__).parameters.values()} - {'config', 'self'}
+        for key in config:
+            if key not in arg_names:
+                raise ValueError(f"Invalid argument '{key}' in config")
+        given = locals()
+        for name in arg_names:
+            if name not in config:
+                config[name] = given[name]
+        self.init_helper(**config)
+
+    def init_helper(self, in_channels, out_channels, edgefeat_dim, embed_dim, learnable_embedding,
+                    encode_vertex_degrees, vertex_degree_encoding_function, vertex_degree_encoding_scale,
+                    learnable_vertex_degree_encoding_scale, homog_degree_encoding, vertex_degree_pad_thresh,
+                    concat_self, message_weight_vs_self, bias, mlp_layers, mlp_hidden_dim, mlp_activation_final,
+                    mlp_activation_hidden, mlp_init, batchNorm_final, batchNorm_hidden, dropout_final, dropout_hidden,
+                    self_loop_weight, edge_weighting, device, dtype):
+        assert edge_weighting in {'unit', 'gcn'}, 'invalid value passed in argument <edge_weighting>'
+        assert vertex_degree_encoding_function in {'identity', 'sqrt', 'log'}, \
+            'invalid value passed in argument <vertex_degree_encoding_function>'
+        if edgefeat_dim > 0:
+            raise NotImplementedError("fsw_gnn_amd: edge features (edgefeat_dim > 0) are not implemented yet (SURVEY.md 8f #2)")
+        if mlp_hidden_dim is None:
+            mlp_hidden_dim = max(in_channels, out_channels)
+        if (mlp_layers == 0) and (concat_self is False):
+            embed_dim = out_channels
+        elif embed_dim is None:
+            embed_dim = 2 * max(in_channels, out_channels)
+        embedding_bias = (bias and mlp_layers == 0)                         # fsw_conv.py:237
+        method = 'homog' if homog_degree_encoding else 'plain'              # fsw_conv.py:240
+
+        self.in_channels, self.out_channels, self.embed_dim = in_channels, out_channels, embed_dim
+        self.edgefeat_dim = edgefeat_dim
+        self.concat_self = concat_self
+        self.edge_weighting = edge_weighting
+        self.self_loop_weight = self_loop_weight
+        self.message_weight_vs_self = message_weight_vs_self
+        mlp_input_dim = in_channels + embed_dim if concat_self else embed_dim
+
+        if mlp_layers == 0:                                                  # fsw_conv.py:255-267
+            self.mlp = None
+            if concat_self:
+                with torch.no_grad():
+                    # the reference additionally runs minimize_mutual_coherence on this matrix (init-time only)
+                    dim_reduct = torch.randn(size=(out_channels, mlp_input_dim), device=device, dtype=dtype)
+                    dim_reduct = torch.nn.functional.normalize(dim_reduct, dim=1)
+                self.dim_reduct = torch.nn.Parameter(dim_reduct, requires_grad=learnable_embedding)
+            self.bn_final = torch.nn.BatchNorm1d(num_features=out_channels, device=device, dtype=dtype) if batchNorm_final else None
+        else:                                                                # fsw_conv.py:269-310
+            self.bn_final = None
+            mods = []
+            for i in range(mlp_layers):
+                last = (i == mlp_layers - 1)
+                in_curr = mlp_input_dim if i == 0 else mlp_hidden_dim
+                out_curr = out_channels if last else mlp_hidden_dim
+                layer = torch.nn.Linear(in_curr, out_curr, bias=bias, device=device, dtype=dtype)
+                if mlp_init is not None:
+                    init = {'xavier_uniform': torch.nn.init.xavier_uniform_, 'xavier_normal': torch.nn.init.xavier_normal_,
+                            'kaiming_uniform': torch.nn.init.kaiming_uniform_, 'kaiming_normal': torch.nn.init.kaiming_normal_}
+                    if mlp_init not in init:
+                        raise RuntimeError('Invalid value passed at argument mlp_init')
+                    init[mlp_init](layer.weight)
+                    if bias:
+                        torch.nn.init.zeros_(layer.bias)
+                mods.append(layer)
+                if (batchNorm_final if last else batchNorm_hidden):
+                    mods.append(torch.nn.BatchNorm1d(num_features=out_curr, device=device, dtype=dtype))
+                act = mlp_activation_final if last else mlp_activation_hidden
+                if act is not None:
+                    mods.append(act)
+                drop = dropout_final if last else dropout_hidden
+                if drop > 0:
+                    mods.append(torch.nn.Dropout(p=drop))
+            self.mlp = torch.nn.Sequential(*mods)
+
+        # defined by the reference and never used in its forward (fsw_conv.py:312); kept for state_dict parity
+        self.size_coeff = torch.nn.Parameter(torch.ones(1, device=device, dtype=dtype) / np.sqrt(embed_dim),
+                                             requires_grad=learnable_embedding)
+        self.fsw_embed = FSW_embedding(d_in=in_channels, d_out=embed_dim, d_edge=edgefeat_dim,
+                                       learnable_slices=learnable_embedding, learnable_freqs=learnable_embedding,
+                                       learnable_total_mass_encoding_scale=learnable_vertex_degree_encoding_scale,
+                                       encode_total_mass=encode_vertex_degrees,
+                                       total_mass_encoding_function=vertex_degree_encoding_function,
+                                       total_mass_encoding_scale=vertex_degree_encoding_scale,
+                                       total_mass_encoding_method=method,
+                                       total_mass_pad_thresh=vertex_degree_pad_thresh,
+                                       minimize_slice_coherence=True, freqs_init='spread',
+                                       enable_bias=embedding_bias, device=device, dtype=dtype)
+        device = device if device is not None else self.fsw_embed.get_device()
+        self.to(device=device, dtype=dtype)
+
+    # ------------------------------------------------------------------------------------------------
+    def build_graph(self, edge_index, num_vertices):
+        """edge_index [2, E] int64 (row 0 = sender, row 1 = recipient) -> CSRGraph.
+
+        Unit weighting without self loops carries no weight array at all (the unit fast path).  Self loops
+        (fsw_conv.py:390-395) append n weighted edges; 'gcn' weighting (fsw_conv.py:406-409) divides every
+        edge by sqrt(deg_recipient) * sqrt(deg_sender) with deg = weighted in-degree.  Parallel edges stay
+        separate elements (see DESIGN.md "duplicates"), which gives the same sums as the reference's coalesce.
+        """
+        src, dst = edge_index[0], edge_index[1]
+        w = None
+        if self.self_loop_weight > 0:
+            loops = torch.arange(num_vertices, device=edge_index.device, dtype=torch.int64)
+            w = torch.cat([torch.ones(src.numel(), device=src.device, dtype=torch.float32),
+                           torch.full((num_vertices,), float(self.self_loop_weight), device=src.device, dtype=torch.float32)])
+            src = torch.cat([src, loops])
+            dst = torch.cat([dst, loops])
+        if self.edge_weighting == 'gcn':
+            if w is None:
+                w = torch.ones(src.numel(), device=src.device, dtype=torch.float32)
+            deg = torch.zeros(num_vertices, device=src.device, dtype=torch.float32).scatter_add_(0, dst, w)
+            ds = torch.sqrt(deg)
+            w = w / ds[dst] / ds[src]
+        return build_csr(dst, src, w, num_vertices, num_vertices)
+
+    def forward(self, vertex_features, edge_index, edge_features=None):
+        """vertex_features [n, in_channels], edge_index [2, E] long -> [n, out_channels] (fsw_conv.py:331-369)."""
+        emb_mod = self.fsw_embed
+        assert vertex_features.dtype == emb_mod.get_dtype(), 'vertex_features has incorrect dtype (expected %s, got %s)' % (emb_mod.get_dtype(), vertex_features.dtype)
+        assert vertex_features.device == emb_mod.get_device(), 'vertex_features has incorrect device (expected %s, got %s)' % (emb_mod.get_device(), vertex_features.device)
+        assert edge_index.device == emb_mod.get_device(), 'edge_index has incorrect device (expected %s, got %s)' % (emb_mod.get_device(), edge_index.device)
+        assert edge_features is None, 'Edge features should not be provided since edgefeat_dim = 0'
+        if vertex_features.device.type != 'cuda':
+            raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
+        if torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in emb_mod.parameters())):
+            raise NotImplementedError("fsw_gnn_amd: the backward pass of the embedding is not implemented yet "
+                                      "(SURVEY.md 8f #1); call forward under torch.no_grad()")
+        n = vertex_features.size(0)
+        x = vertex_features.contiguous()
+        graph = self.build_graph(edge_index, n)
+        E = self.embed_dim
+        width = E + self.in_channels if self.concat_self else E
+        buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
+        scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
+        if getattr(self, '_slice_parallel', False):
+            from .dist import sharded_embed_into
+            sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=self._slice_parallel_group)
+        else:
+            emb_mod.embed_into(x, graph, buf, out_scale=scale)
+        if self.concat_self:
+            buf[:, E:] = x
+        if self.mlp is not None:
+            out = self.mlp(buf)
+        elif self.concat_self:
+            out = torch.matmul(buf, self.dim_reduct.transpose(0, 1))
+        else:
+            out = buf
+        if self.bn_final is not None:
+            out = self.bn_final(out)
+        return out
+
+    def enable_slice_parallel(self, group=None, enabled=True):
+        """Shard the slice axis of the embedding over the ranks of `group` (dist.py); one all-gather per forward."""
+        self._slice_parallel = bool(enabled)
+        self._slice_parallel_group = group
+        return self
+
+    # the reference defines these as empty stubs and never calls propagate() (fsw_conv.py:374-381)
+    def aggregate(self, inputs, index):
+        return
+
+    def message(self, x_j):
+        return
+
+    def update(self, aggr_out):
+        return
+
+
+@register_pooling('fsw_readout')
+class FSW_readout(FSW_conv):
+    def forward(self, vertex_features, graph_index=None, batch_size=None):
+        """Global pooling: every vertex sends to the node of its graph (reference fsw_conv.py:451-517)."""
+        assert self.edgefeat_dim == 0, 'edgefeat_dim should equal zero in a global readout layer'
+        num_vertices = vertex_features.shape[0]
+        if graph_index is None:
+            assert batch_size is None, 'batch_size must be None when graph_index is None'
+            graph_index = torch.zeros(num_vertices, device=vertex_features.device, dtype=torch.int64)
+        else:
+            assert tuple(graph_index.shape) == (num_vertices,), 'graph_index should be of shape (num_vertices,)'
+            assert graph_index.dtype == torch.int64, 'invalid dtype given in graph_index'
+        if batch_size is None:
+            batch_size = int(graph_index.max().item()) + 1
+        emb_mod = self.fsw_embed
+        assert vertex_features.device == emb_mod.get_device() and graph_index.device == emb_mod.get_device()
+        assert vertex_features.dtype == emb_mod.get_dtype()
+        src = torch.arange(num_vertices, device=vertex_features.device, dtype=torch.int64)
+        graph = build_csr(graph_index.contiguous(), src, None, batch_size, num_vertices)
+        emb = torch.empty((batch_size, self.embed_dim), dtype=vertex_features.dtype, device=vertex_features.device)
+        emb_mod.embed_into(vertex_features.contiguous(), graph, emb)
+        if graph.flags & 1:
+            raise AssertionError('all entries of graph_index must be in the range 0,...,batch_size-1')
+        if self.mlp is not None:
+            return self.mlp(emb)
+        if self.concat_self:
+            return torch.matmul(emb, self.dim_reduct.transpose(0, 1))
+        return emb

@@ -1,0 +1,453 @@
+"""FSW_embedding: host-side mirror of the reference's FSW_embedding module (reference fsw_embedding.py:169-1144)
+over the hand-written HIP kernels of libfsw_hip.so.
+
+Same constructor arguments, parameter names (projVecs, freqs, bias, total_mass_encoding_scale -- state_dict
+compatible, reference fsw_embedding.py:397-409), forward signature and assertion messages as the reference.
+The computation is NOT the reference's chain of torch.sparse_coo operations: forward() builds a CSR adjacency
+(graph.py), projects the points with fp32 MFMA (fsw_project_f32) and runs the fused per-neighbourhood
+sort + cumulative-sum + Fourier readout kernels (fsw_embed_f32).  There is no CPU or pure-PyTorch fallback:
+tensors must live on a HIP device and the native library must be present.
+
+Not implemented in this round (raise NotImplementedError): d_edge > 0 (edge features), Cartesian mode
+(nSlices x nFreqs), autograd backward, mutual-coherence minimisation at initialisation (the flag is accepted,
+slices stay random unit vectors).
+"""
+import ctypes
+import numbers
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .graph import CSRGraph, build_csr
+
+version = "0.1-mi355x"
+
+# Same role as the reference's module flag (fsw_embedding.py:109): validate user input on every forward.
+# The checks are fused into the HIP kernels (flags word read back once), not separate isnan/isinf scans.
+fsw_embedding_basic_safety_checks = True
+
+_MASS_FN = {"identity": 0, "sqrt": 1, "log": 2}
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class FSW_embedding(nn.Module):
+    def __init__(self,
+                 d_in, d_out=None, nSlices=None, nFreqs=None, collapse_freqs=False,
+                 d_edge=0,
+                 encode_total_mass=False,
+                 total_mass_encoding_function='identity',
+                 total_mass_encoding_scale=1.0,
+                 total_mass_encoding_method='plain',
+                 total_mass_pad_thresh=1.0,
+                 learnable_slices=False, learnable_freqs=False, learnable_total_mass_encoding_scale=False,
+                 freqs_init='random',
+                 minimize_slice_coherence=False,
+                 enable_bias=True,
+                 device=None, dtype=torch.float32,
+                 load_custom_cuda_lib=True,
+                 report=False, user_warnings=True,
+                 report_on_coherence_minimization=False):
+        super().__init__()
+        self.user_warnings = user_warnings
+        # reference fsw_embedding.py:195-206 loads its CUDA library here; this build cannot run without its
+        # native library, so load_custom_cuda_lib=False is rejected instead of selecting a slow path.
+        if not load_custom_cuda_lib:
+            raise RuntimeError("fsw_gnn_amd has no pure-PyTorch path: load_custom_cuda_lib=False is not supported")
+        _lib.lib()
+
+        assert d_in >= 0, 'd_in must be nonnegative'
+        assert d_edge >= 0, 'd_edge must be nonnegative'
+        assert (d_out is None) or (d_out >= 0), 'd_out must be nonnegative or None'
+        if d_out == 0:
+            encode_total_mass = False
+        self.d_in, self.d_edge = d_in, d_edge
+        self.encode_total_mass = bool(encode_total_mass)
+        self.total_mass_encoding_dim = 1 if self.encode_total_mass else 0
+        self.total_mass_encoding_scale_init = total_mass_encoding_scale
+
+        total_mass_pad_thresh = float(total_mass_pad_thresh)
+        assert not np.isinf(total_mass_pad_thresh), 'total_mass_pad_thresh cannot be inf'
+        assert not np.isnan(total_mass_pad_thresh), 'total_mass_pad_thresh cannot be NaN'
+        assert total_mass_pad_thresh > 0, 'total_mass_pad_thresh must be positive'
+        self.total_mass_pad_thresh = total_mass_pad_thresh
+        assert total_mass_encoding_method in {'plain', 'homog', 'homog_alt'}, \
+            "<total_mass_encoding_method> must be one of 'plain', 'homog', 'homog_alg'"
+        self.total_mass_encoding_method = total_mass_encoding_method
+        assert total_mass_encoding_function in {'identity', 'sqrt', 'log'}, \
+            "<total_mass_encoding_function> must be one of 'identity', 'sqrt', 'log'"
+        self.total_mass_encoding_function = total_mass_encoding_function
+
+        # size logic: reference fsw_embedding.py:242-261
+        if (d_out is not None) and (nSlices is None) and (nFreqs is None):
+            self.cartesian_mode = False
+            self.collapse_freqs = False
+            self.d_out = d_out
+            self.nSlices = d_out - self.total_mass_encoding_dim
+            self.nFreqs = d_out - self.total_mass_encoding_dim
+        elif (d_out is None) and (nSlices is not None) and (nFreqs is not None):
+            raise NotImplementedError("fsw_gnn_amd: Cartesian mode (nSlices x nFreqs) is out of scope (SURVEY.md 2, #14)")
+        else:
+            assert False, "Expected exactly one of (d_out != None) or (nSlices != None and nFreqs != None)"
+        assert self.d_out >= 0, 'd_out must be nonnegative'
+        if d_edge > 0:
+            raise NotImplementedError("fsw_gnn_amd: edge features (d_edge > 0) are not implemented yet (SURVEY.md 8f #2)")
+
+        self.minimize_slice_coherence = minimize_slice_coherence
+        self.learnable_slices = learnable_slices
+        self.learnable_freqs = learnable_freqs
+        self.learnable_total_mass_encoding_scale = learnable_total_mass_encoding_scale
+        self.freqs_init = freqs_init
+        self.enable_bias = enable_bias
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device_new = torch.device(device)
+        assert dtype.is_floating_point and (not dtype.is_complex), \
+            'dtype must be real floating-point; instead got dtype=%s' % (dtype)
+        if dtype != torch.float32:
+            raise NotImplementedError("fsw_gnn_amd: the HIP kernels compute in float32 (got dtype=%s)" % dtype)
+        self.dtype_new = dtype
+        self.report = report
+        self.report_on_coherence_minimization = report_on_coherence_minimization
+        if report:
+            print('Fourier Sliced-Wasserstein Embedding, MI355X-native build %s' % version)
+            print('Using %d (slice, frequency) pairs; device: %s    dtype: %s' % (self.nSlices, self.device_new, dtype))
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------------------------------------
+    def reset_parameters(self, freqs_init=None, minimize_slice_coherence=None, report=None,
+                         report_on_coherence_minimization=None):
+        """Reference fsw_embedding.py:343-414 / 445-559 (parameter semantics; RNG values differ)."""
+        self.freqs_init = self.freqs_init if freqs_init is None else freqs_init
+        if minimize_slice_coherence is not None:
+            self.minimize_slice_coherence = minimize_slice_coherence
+        if report is not None:
+            self.report = report
+        if hasattr(self, 'device_new'):
+            device = self.device_new
+            delattr(self, 'device_new')
+        else:
+            device = self.get_device()
+        if hasattr(self, 'dtype_new'):
+            dtype = self.dtype_new
+            delattr(self, 'dtype_new')
+        else:
+            dtype = self.get_dtype()
+        projVecs, freqs, bias, scale = FSW_embedding.generate_embedding_parameters(
+            d_in=self.d_in + self.d_edge, nSlices=self.nSlices, nFreqs=self.nFreqs,
+            total_mass_encoding_dim=self.total_mass_encoding_dim,
+            total_mass_encoding_scale_init=self.total_mass_encoding_scale_init, freqs_init=self.freqs_init, device=device)
+        self.projVecs = nn.Parameter(projVecs.to(dtype=dtype, device=device), requires_grad=self.learnable_slices)
+        self.freqs = nn.Parameter(freqs.to(dtype=dtype, device=device), requires_grad=self.learnable_freqs)
+        if self.enable_bias:
+            self.bias = nn.Parameter(bias.to(dtype=dtype, device=device), requires_grad=self.learnable_slices)
+        if self.encode_total_mass:
+            self.total_mass_encoding_scale = nn.Parameter(scale.to(dtype=dtype), requires_grad=self.learnable_total_mass_encoding_scale)
+        return self
+
+    @staticmethod
+    def generate_embedding_parameters(d_in, nSlices, nFreqs, total_mass_encoding_dim, total_mass_encoding_scale_init,
+                                      freqs_init, device):
+        dt = torch.float64
+        # A. random unit projection vectors (reference :448-456).  minimize_mutual_coherence (:464, :3045-3248) is
+        #    an init-time O(S^2 d) optimisation outside the hot path and is not ported.
+        projVecs = torch.randn(size=(nSlices, d_in), dtype=dt, device=device)
+        projVecs = nn.functional.normalize(projVecs, p=2.0, dim=1, eps=0)
+        if nSlices > 0 and d_in > 0:
+            assert not torch.isinf(projVecs).any(), "Found infs in projVecs"
+            assert not torch.isnan(projVecs).any(), "Found nans in projVecs"
+        # B. frequencies (reference :489-535)
+        shape = (nFreqs,)
+        if nFreqs == 0:
+            freqs = torch.zeros(size=shape, dtype=dt, device=device)
+        elif isinstance(freqs_init, numbers.Real):
+            assert not np.isinf(freqs_init), 'freqs_init cannot be infinite'
+            assert not np.isnan(freqs_init), 'freqs_init cannot be NaN'
+            freqs = freqs_init * torch.ones(size=shape, dtype=dt, device=device)
+        elif isinstance(freqs_init, tuple):
+            assert (len(freqs_init) == 2), 'When freqs_init is a tuple, it must be of length 2'
+            a, b = freqs_init
+            assert not np.isinf(a) and not np.isinf(b), 'Received infinite value in freqs_init tuple'
+            assert not np.isnan(a) and not np.isnan(b), 'Received NaN value in freqs_init tuple'
+            assert a <= b, 'When freqs_init is a tuple, it is required to satisfy freqs_init[0] <= freqs_init[1]'
+            if nFreqs == 1:
+                freqs = a + (b - a) / 2 * torch.ones(size=shape, dtype=dt, device=device)
+            else:
+                freqs = a + (b - a) * (torch.arange(nFreqs, dtype=dt, device=device) / (nFreqs - 1))
+        elif freqs_init == 'random':
+            freqs = torch.rand(size=shape, dtype=dt, device=device)
+            freqs, _ = torch.sort(freqs, dim=0)
+            freqs = freqs / (1 - freqs)
+        elif freqs_init == 'spread':
+            freqs = (0.5 + torch.arange(nFreqs, dtype=dt, device=device)) / nFreqs
+            freqs = freqs / (1 - freqs)
+        else:
+            raise RuntimeError("Invalid value for argument freqs_init; expected number, tuple (a,b) of numbers "
+                               "denoting an interval, 'random' or 'spread'")
+        if nFreqs > 0:
+            assert not torch.isinf(freqs).any(), "Found infs in freqs"
+            assert not torch.isnan(freqs).any(), "Found nans in freqs"
+        # C. zero bias (reference :542-550) and the total-mass scale
+        bias = torch.zeros(size=(nSlices + total_mass_encoding_dim,), dtype=dt, device=device)
+        scale = torch.tensor(total_mass_encoding_scale_init, device=device, dtype=dt) if total_mass_encoding_dim > 0 else None
+        return projVecs, freqs, bias, scale
+
+    def spread_freqs_at_interval(self, center, radius):
+        """Reference fsw_embedding.py:567-582."""
+        assert radius >= 0
+        if (self.nFreqs == 1) or (radius == 0):
+            freqs_new = center * torch.ones_like(self.freqs)
+        else:
+            spread = 2 * (0.5 + torch.arange(self.nFreqs, dtype=self.get_dtype(), device=self.get_device())) / self.nFreqs - 1
+            spread = spread * 1 / (1 - 1 / self.nFreqs)
+            freqs_new = center + radius * spread
+        sd = self.state_dict()
+        sd['freqs'] = freqs_new
+        self.load_state_dict(sd)
+        return self
+
+    def get_device(self):
+        return self.projVecs.device
+
+    def _mass_scale_host(self):
+        """Host value of the total-mass scale, re-read from the device only when the parameter changed."""
+        p = self.total_mass_encoding_scale
+        key = (p.data_ptr(), p._version)
+        if getattr(self, '_mass_scale_cache', (None, None))[0] != key:
+            self._mass_scale_cache = (key, float(p.detach()))
+        return self._mass_scale_cache[1]
+
+    def get_dtype(self):
+        return self.projVecs.dtype
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, X, W='unit', X_edge=None, graph_mode=False, serialize_num_slices=None):
+        """Same contract as the reference forward (fsw_embedding.py:587-890).
+
+        X (<batch>, n, d_in); W (<batch>, n) | 'unit' | 'uniform'; graph_mode: W (<batch>, nRecipients, n) dense or
+        coalesced torch.sparse_coo, X shared by the recipients.  Returns (<batch>, [nRecipients,] d_out).
+        """
+        assert self.total_mass_pad_thresh > 0, 'total_mass_pad_thresh must be positive'
+        assert (X_edge is None) or (X_edge.numel() == 0), 'X_edge should be None or empty since d_edge == 0'
+        assert torch.is_tensor(X), 'X must be a pytorch tensor. Instead got type %s' % (type(X))
+        assert torch.is_tensor(W) or W in {'unit', 'uniform'}, "W must be a pytorch tensor, 'unit' or 'uniform'"
+        assert X.dtype == self.get_dtype(), ("X has the wrong dtype. Expected %s, got %s" % (self.get_dtype(), X.dtype))
+        assert X.device == self.get_device(), ("X is on the wrong device. Expected %s, got %s" % (self.get_device(), X.device))
+        if X.device.type != 'cuda':
+            raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
+        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())
+                                        or (torch.is_tensor(W) and W.requires_grad)):
+            raise NotImplementedError("fsw_gnn_amd: the backward pass is not implemented yet (SURVEY.md 8f #1); "
+                                      "call forward under torch.no_grad()")
+        if torch.is_tensor(W):
+            assert W.dtype == self.get_dtype(), ("W has the wrong dtype. Expected %s, got %s" % (self.get_dtype(), W.dtype))
+            assert W.device == self.get_device(), ("W is on the wrong device. Expected %s, got %s" % (self.get_device(), W.device))
+            if W.is_sparse or W.layout != torch.strided:
+                assert W.layout == torch.sparse_coo, ("Sparse W has an unsupported sparsity layout '%s'. Only the COO "
+                                                      "layout (torch.sparse_coo) is currently supported." % (W.layout))
+                assert W.is_coalesced(), 'Sparse W must be coalesced'
+                assert W.dense_dim() == 0, 'W.dense_dim() must be zero'
+        assert len(X.shape) >= 2, "X must be a tensor of order at least 2"
+        assert X.shape[-1] == self.d_in, "The last dimension of X must equal d_in=%d. Instead got %d" % (self.d_in, X.shape[-1])
+
+        d = self.d_in
+        if not graph_mode:
+            batch_dims = tuple(X.shape[0:-2])
+            n = X.shape[-2]
+            B = int(np.prod(batch_dims)) if batch_dims else 1
+            if torch.is_tensor(W):
+                assert (len(W.shape) == len(X.shape) - 1) and (tuple(W.shape) == tuple(X.shape[0:-1])), \
+                    "Shape mismatch between X and W: If X.shape = (b1,b2,...,bk,n,d_in) then W.shape should be (b1,b2,...,bk,n) (unless graph_mode=True)"
+                assert not W.is_sparse, "sparse W requires graph_mode=True in this build"
+                wvals = W.reshape(-1)
+            elif W == 'unit':
+                wvals = None
+            else:  # 'uniform'
+                wvals = torch.full((B * n,), 1.0 / n, dtype=self.get_dtype(), device=X.device)
+            rec = torch.arange(B, device=X.device, dtype=torch.int64).repeat_interleave(n)
+            snd = torch.arange(B * n, device=X.device, dtype=torch.int64)
+            Xf = X.reshape(B * n, d)
+            num_rows, out_shape = B, batch_dims
+        else:
+            assert torch.is_tensor(W), 'W must be explicitly provided when graph_mode=True'
+            batch_dims = tuple(W.shape[0:-2])
+            nR, n = W.shape[-2], W.shape[-1]
+            assert (len(W.shape) == len(X.shape)) and (W.shape[-1] == X.shape[-2]) and (tuple(W.shape[0:-2]) == tuple(X.shape[0:-2])), \
+                "Shape mismatch between X and W: When graph_mode=True, if W.shape = (b1,b2,...,bk,nRecipients,n) then X.shape should be (b1,b2,...,bk,n,d_in)"
+            B = int(np.prod(batch_dims)) if batch_dims else 1
+            if W.is_sparse:
+                idx, wvals = W.indices(), W.values()
+            else:
+                idx = W.nonzero(as_tuple=False).t().contiguous()
+                wvals = W[tuple(idx)]
+            if batch_dims:
+                strides = torch.tensor(list(np.cumprod((batch_dims + (1,))[::-1])[::-1][1:]), device=X.device, dtype=torch.int64)
+                b = (idx[:len(batch_dims)] * strides[:, None]).sum(0)
+            else:
+                b = 0
+            rec = (b * nR + idx[-2]).contiguous()
+            snd = (b * n + idx[-1]).contiguous()
+            Xf = X.reshape(B * n, d)
+            num_rows, out_shape = B * nR, batch_dims + (nR,)
+
+        graph = build_csr(rec, snd, wvals, num_rows, Xf.shape[0])
+        out = torch.empty((num_rows, self.d_out), dtype=X.dtype, device=X.device)
+        self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
+        return out.reshape(out_shape + (self.d_out,))
+
+    # ------------------------------------------------------------------------------------------------
+    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None):
+        """Writes out_scale * E(X, graph) into the left columns of `out` (row stride out.stride(0)).
+
+        X [num_cols, d_in] float32 contiguous; out [num_rows, >= width] float32 with unit inner stride, where
+        width = d_out, or total_mass_dim + (kb - ka) when slice_range = (ka, kb) restricts the call to a block of
+        slices (multi-GPU slice sharding, dist.py: column 0 is still the total-mass column, then slices ka..kb-1).
+        This is the hot path: projection (MFMA) -> coefficient table -> fused neighbourhood kernels.
+        """
+        L = _lib.lib()
+        dev = X.device
+        has_mass = 1 if self.encode_total_mass else 0
+        ka, kb = (0, self.nSlices) if slice_range is None else slice_range
+        assert 0 <= ka < kb <= self.nSlices or self.d_out == 0, 'bad slice_range'
+        S = kb - ka
+        partial = (ka, kb) != (0, self.nSlices)
+        assert X.is_contiguous() and out.stride(1) == 1 and out.shape[0] == graph.num_rows and out.shape[1] >= has_mass + S
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.d_out == 0:
+            return out
+        if self.nSlices == 0:
+            raise NotImplementedError("fsw_gnn_amd: nSlices == 0 with encode_total_mass is not supported")
+        method = self.total_mass_encoding_method
+        plain = (not self.encode_total_mass) or method == 'plain'
+        if partial and not plain:
+            raise NotImplementedError("slice sharding supports total_mass_encoding_method='plain' only")
+        bias = self.bias.detach() if (self.enable_bias and plain) else None
+        if bias is not None and partial:
+            bias = torch.cat([bias[:has_mass], bias[has_mass + ka:has_mass + kb]])
+        mass_scale = self._mass_scale_host() if self.encode_total_mass else 1.0
+        unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0
+
+        step = S if (serialize_num_slices is None or serialize_num_slices >= S) else int(serialize_num_slices)
+        assert step >= 1, 'serialize_num_slices must be None or a positive integer'
+        ldp = _round_up(step, 64)
+        Xp = torch.empty((X.shape[0], ldp), dtype=torch.float32, device=dev)
+        V = self.projVecs.detach()[ka:kb]
+        freqs = self.freqs.detach()[ka:kb]
+        table = None
+        if unit_fast:
+            table = torch.empty((int(L.fsw_unit_table_rows(_lib.REG_MAX_DEG)), ldp), dtype=torch.float32, device=dev)
+        st = scratch = None
+        for k0 in range(0, S, step):
+            k1 = min(S, k0 + step)
+            Sc = k1 - k0
+            Vc = V[k0:k1]
+            rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
+                                   _lib.ptr(Xp), ldp, _lib.ptr(graph.stats_dev) if k0 == 0 else None, stream)
+            _lib.check(rc, "fsw_project_f32")
+            if st is None:
+                # one device->host read per forward: validation flags (fused into the kernels) + degree classes
+                st = graph.stats()
+                if fsw_embedding_basic_safety_checks:
+                    fl = st[_lib.STAT_FLAGS]
+                    assert not (fl & _lib.FLAG_INDEX_RANGE), "adjacency index out of range"
+                    assert not (fl & _lib.FLAG_X_NONFINITE), "The entries of X cannot contain NaNs or infs"
+                    assert not (fl & _lib.FLAG_W_NONFINITE), "All entries of W must be finite"
+                    assert not (fl & _lib.FLAG_W_NEGATIVE), "All entries of W must be nonnegative"
+                if st[_lib.STAT_NUM_GLOBAL] > 0:
+                    scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=dev)
+            fc = freqs[k0:k1]
+            if unit_fast:
+                rc = L.fsw_unit_coeff_table(_lib.ptr(fc), Sc, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
+                _lib.check(rc, "fsw_unit_coeff_table")
+            first = (k0 == 0)
+            hm = has_mass if first else 0          # the first chunk also writes the total-mass column
+            col0 = 0 if first else has_mass + k0   # first destination column of this chunk
+            a = _lib.EmbedArgs()
+            a.rowptr, a.col = graph.rowptr.data_ptr(), graph.col.data_ptr()
+            a.w = graph.w.data_ptr() if graph.w is not None else None
+            a.perm, a.bin_start, a.num_rows = graph.perm.data_ptr(), graph.bin_start.data_ptr(), graph.num_rows
+            a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, fc.data_ptr(), Sc, float(self.total_mass_pad_thresh)
+            a.unit_table, a.ldt = (table.data_ptr() if table is not None else None), ldp
+            a.out, a.ldo = out.data_ptr() + 4 * col0, out.stride(0)
+            a.bias = (bias.data_ptr() + 4 * col0) if bias is not None else None
+            a.out_scale, a.has_mass = float(out_scale), hm
+            a.mass_fn, a.mass_scale = _MASS_FN[self.total_mass_encoding_function], mass_scale
+            a.num_reg_rows, a.num_lds_rows = st[_lib.STAT_NUM_REG], st[_lib.STAT_NUM_LDS]
+            a.num_global_rows, a.num_zero_rows = st[_lib.STAT_NUM_GLOBAL], st[_lib.STAT_NUM_ZERO]
+            a.max_degree = st[_lib.STAT_MAX_DEGREE]
+            a.scratch = scratch.data_ptr() if scratch is not None else None
+            a.scratch_bytes = scratch.numel() if scratch is not None else 0
+            rc = L.fsw_embed_f32(ctypes.byref(a), stream)
+            _lib.check(rc, "fsw_embed_f32")
+
+        if not plain:
+            # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): rarely used epilogues, done with
+            # three elementwise torch ops on the kernel's 'plain' output (the kernel wrote f(m)*scale in column 0)
+            emb = out[:, 1:self.d_out]
+            tm = out[:, 0:1] / out_scale
+            norm = emb.abs().mean(dim=-1, keepdim=True) / out_scale
+            if method == 'homog':
+                out[:, 0:1] = out_scale * tm * norm
+            else:
+                out[:, 0:1] = out_scale * torch.where(tm <= 1, tm * (2 - tm), torch.ones_like(tm)) * norm
+                emb.mul_(torch.where(tm <= 1, tm.square(), 2 * tm - 1))
+            if self.enable_bias:
+                out[:, :self.d_out] += out_scale * self.bias.detach()
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# segmented cumulative sum: public signature of the reference (fsw_embedding.py:2795)
+# ----------------------------------------------------------------------------------------------------
+def segcumsum(values, segment_ids, max_seg_size=None, in_place=False, thorough_verify_input=False,
+              always_use_pure_torch=False, reverse=False):
+    """Inclusive scan of `values` restarted wherever consecutive `segment_ids` differ (HIP, stream-ordered).
+
+    Keeps the reference signature; max_seg_size is accepted and unused (the scan is single-level), and
+    always_use_pure_torch=True is rejected because this build has no PyTorch path.
+    """
+    assert values.dim() == 1, 'values must be a 1-dimensional tensor'
+    assert segment_ids.dim() == 1, 'segment_ids must be a 1-dimensional tensor'
+    assert segment_ids.numel() == values.numel(), 'values and segment_ids must contain the same number of elements'
+    assert segment_ids.dtype in (torch.int32, torch.int64), 'segment_ids must have int32 or int64 dtype'
+    assert values.device == segment_ids.device, 'values and segment_ids must be on the same device'
+    assert not segment_ids.is_sparse, 'segment_ids cannot be sparse'
+    assert segment_ids.is_contiguous(), 'segment_ids must be in contiguous format'
+    assert not values.is_sparse, 'values cannot be sparse'
+    assert (not in_place) or values.is_contiguous(), 'when in_place==True, values must be in contiguous format'
+    if max_seg_size is not None:
+        assert isinstance(max_seg_size, numbers.Number)
+        assert max_seg_size >= 1
+    if always_use_pure_torch:
+        raise RuntimeError("fsw_gnn_amd has no pure-PyTorch path: always_use_pure_torch=True is not supported")
+    if values.device.type != 'cuda':
+        raise RuntimeError("fsw_gnn_amd.segcumsum: tensors must live on a HIP device (no CPU path)")
+    if values.dtype == torch.float32:
+        dtype_num = 0
+    elif values.dtype == torch.float64:
+        dtype_num = 1
+    else:
+        raise RuntimeError("Unsupported input_tensor dtype ''%s''" % (str(values.dtype)))
+    if thorough_verify_input:
+        _, cc = torch.unique_consecutive(segment_ids, return_counts=True)
+        _, ct = torch.unique(segment_ids, return_counts=True)
+        assert cc.numel() == ct.numel(), 'repeated segment IDs detected'
+        assert not torch.isinf(values).any(), "Found infs in ''values''"
+        assert not torch.isnan(values).any(), "Found nans in ''values''"
+    L = _lib.lib()
+    src = values.contiguous()
+    out = src if in_place else torch.empty_like(src)
+    n = src.numel()
+    if n == 0:
+        return out
+    ws_bytes = int(L.fsw_segcumsum_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=values.device)
+    stream = torch.cuda.current_stream(values.device).cuda_stream
+    rc = L.fsw_segcumsum(dtype_num, _lib.ptr(src), _lib.ptr(out), _lib.ptr(segment_ids), segment_ids.element_size(), n,
+                         1 if reverse else 0, _lib.ptr(ws), ws_bytes, stream)
+    _lib.check(rc, "fsw_segcumsum")
+    return out

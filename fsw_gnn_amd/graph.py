@@ -1,0 +1,72 @@
+"""Adjacency handling: edge list -> CSR by recipient + degree bins, on the GPU (csrc/graph_build.hip).
+
+Stands where the reference builds a coalesced torch.sparse_coo adjacency and repeatedly sorts its int64
+COO keys (FSW_conv.edge_index_to_adj, reference fsw_conv.py:384-447; sp.get_slice_info, reference
+fsw_embedding.py:2586-2678).
+"""
+import torch
+
+from . import _lib
+
+
+class CSRGraph:
+    """Device-resident CSR adjacency adj[recipient, sender] with rows bucketed by in-degree.
+
+    rowptr int32[num_rows+1], col int32[nnz], w float32[nnz] or None (unit weights),
+    perm int32[num_rows] (rows ordered by degree bin), bin_start int32[NUM_BINS+1],
+    stats_dev int32[NUM_STATS] (device) -- read back once per forward by `stats()`.
+    """
+
+    def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev):
+        self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
+        self.rowptr, self.col, self.w, self.perm, self.bin_start = rowptr, col, w, perm, bin_start
+        self.stats_dev = stats_dev
+        self._stats = None
+
+    def stats(self):
+        """Host copy of the stats words (one small device->host copy; synchronises the stream)."""
+        if self._stats is None:
+            self._stats = self.stats_dev.cpu().tolist()
+        return self._stats
+
+    @property
+    def flags(self):
+        return self.stats()[_lib.STAT_FLAGS]
+
+    @property
+    def max_degree(self):
+        return self.stats()[_lib.STAT_MAX_DEGREE]
+
+    def in_degrees(self):
+        """Number of incoming edges per row (with multiplicity), float32 -- fsw_conv.py:400-401."""
+        return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+
+
+def build_csr(recipients, senders, edge_w, num_rows, num_cols):
+    """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights)."""
+    L = _lib.lib()
+    dev = recipients.device
+    if dev.type != "cuda":
+        raise RuntimeError("fsw_gnn_amd.build_csr: tensors must live on a HIP device (no CPU path)")
+    assert recipients.dtype == torch.int64 and senders.dtype == torch.int64, "edge endpoints must be int64"
+    assert recipients.dim() == 1 and recipients.shape == senders.shape
+    recipients = recipients.contiguous()
+    senders = senders.contiguous()
+    E = recipients.numel()
+    if edge_w is not None:
+        assert edge_w.dtype == torch.float32 and edge_w.shape == recipients.shape and edge_w.device == dev
+        edge_w = edge_w.contiguous()
+    rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    w = torch.empty(max(E, 1), dtype=torch.float32, device=dev) if edge_w is not None else None
+    perm = torch.empty(num_rows, dtype=torch.int32, device=dev)
+    bin_start = torch.empty(_lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
+    stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
+    ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.fsw_graph_build(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols,
+                           _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(bin_start),
+                           _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
+    _lib.check(rc, "fsw_graph_build")
+    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats)

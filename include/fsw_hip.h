@@ -1,0 +1,161 @@
+/* fsw_hip.h -- C ABI of libfsw_hip.so: the MI355X (gfx950) native hot path of FSW_conv / FSW_embedding.
+ *
+ * Drop-in boundary.  The reference's only native code is libfsw_embedding.so, loaded with ctypes
+ * (reference fsw_embedding.py:94-99, 195-206) and called with raw tensor.data_ptr() device pointers
+ * from segcumsum_cuda (fsw_embedding.py:2878-3012).  This library is loaded the same way and keeps the
+ * same conventions -- plain pointers and sizes, caller-owned pre-allocated buffers, no torch types --
+ * with three deliberate changes:
+ *   - every entry point is stream-ordered (takes a hipStream_t) and never device-synchronises
+ *     (the reference wrappers cudaDeviceSynchronize() before and after each launch,
+ *      fsw_embedding.cu:197, 208, 215, 227, and use the default stream);
+ *   - every entry point returns an int status (0 = ok); nothing prints-and-exit(1)s
+ *     (fsw_embedding.cu:20-27).  fsw_last_error() returns the message of the last failure;
+ *   - besides the segmented cumsum, the whole chain the reference builds out of ~15 E*S-sized COO
+ *     tensors (fsw_embedding.py:894-1112: projection, per-slice sort, weight permutation, segmented
+ *     cumsum, sinc/cos readout, reduction) is exported as fused kernels on a CSR adjacency.
+ *
+ * The three legacy symbols at the end keep the reference's exact signatures, so the reference's own
+ * fsw_embedding.py can dlopen this library in place of libfsw_embedding.so unchanged.
+ *
+ * All pointers are DEVICE pointers unless stated otherwise.  Index type is int32: num_rows, num_cols
+ * and num_edges must each be < 2^31.
+ */
+#ifndef FSW_HIP_H
+#define FSW_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
+
+#define FSW_ABI_VERSION 1
+
+/* Degree classes of the fused neighbourhood kernels.  Rows are binned by in-degree:
+ *   bin b, 0 <= b <= FSW_REG_MAX_DEG : rows of degree exactly b (register path, one wave per row and
+ *                                      64-slice chunk, exact-size sorting network)
+ *   bin FSW_BIN_LDS                  : FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (LDS bitonic path)
+ *   bin FSW_BIN_GLOBAL               : degree > FSW_LDS_MAX_DEG (global-scratch bitonic path)        */
+#define FSW_REG_MAX_DEG 32
+#define FSW_LDS_MAX_DEG 2048
+#define FSW_BIN_LDS (FSW_REG_MAX_DEG + 1)
+#define FSW_BIN_GLOBAL (FSW_REG_MAX_DEG + 2)
+#define FSW_NUM_BINS (FSW_REG_MAX_DEG + 3)
+
+/* stats[] words written by fsw_graph_build / fsw_project_f32 (device int32[FSW_NUM_STATS]) */
+#define FSW_STAT_FLAGS 0        /* OR of FSW_FLAG_* */
+#define FSW_STAT_MAX_DEGREE 1
+#define FSW_STAT_NUM_ZERO_DEG 2
+#define FSW_STAT_NUM_REG 3      /* rows with 1 <= degree <= FSW_REG_MAX_DEG */
+#define FSW_STAT_NUM_LDS 4
+#define FSW_STAT_NUM_GLOBAL 5
+#define FSW_STAT_GLOBAL_PAD_ELEMS 6 /* sum over global-path rows of pow2ceil(degree + 1), saturating */
+#define FSW_NUM_STATS 8
+
+#define FSW_FLAG_INDEX_RANGE 1   /* an edge endpoint outside [0, num_rows) x [0, num_cols) */
+#define FSW_FLAG_W_NONFINITE 2   /* reference assert fsw_embedding.py:678-679 */
+#define FSW_FLAG_W_NEGATIVE 4    /* reference assert fsw_embedding.py:680 */
+#define FSW_FLAG_X_NONFINITE 8   /* reference assert fsw_embedding.py:652-653 */
+
+int fsw_abi_version(void);
+const char* fsw_arch(void);       /* "gfx950" */
+const char* fsw_last_error(void); /* host string, valid until the next failing call on this thread */
+
+/* ---- adjacency: edge list -> CSR by recipient, plus degree bins ---------------------------------
+ * Replaces FSW_conv.edge_index_to_adj (reference fsw_conv.py:384-447: torch.sparse_coo_tensor().coalesce()
+ * + sp.get_slice_info) and the sp.get_slice_info(W, -1) / concat_sparse sorts of FSW_embedding.forward
+ * (fsw_embedding.py:778-821).  Parallel edges are kept as separate elements: k parallel unit edges
+ * j->i contribute exactly what the reference's single coalesced entry of weight k contributes, because
+ * the Fourier readout telescopes over equal projections (DESIGN.md "duplicates").
+ *   recipients/senders : int64[num_edges]  (edge_index row 1 / row 0; COO indices row 0 / row 1)
+ *   edge_w             : float[num_edges] or NULL for unit weights
+ *   rowptr int32[num_rows+1], col int32[num_edges], w float[num_edges] (ignored if edge_w NULL)
+ *   perm int32[num_rows]  rows ordered by degree bin; bin_start int32[FSW_NUM_BINS+1] offsets into perm
+ *   stats int32[FSW_NUM_STATS] (zeroed by this call)                                               */
+size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges);
+int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w,
+                    int64_t num_edges, int64_t num_rows, int64_t num_cols,
+                    int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* bin_start,
+                    int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
+
+/* ---- projection: Xp[n, ldp] = X[n, ldx] . V[S, ldv]^T, fp32 MFMA (v_mfma_f32_32x32x2_f32) -------
+ * Replaces torch.tensordot(X, projVecs) (reference fsw_embedding.py:909-913).  Sets
+ * FSW_FLAG_X_NONFINITE in stats[FSW_STAT_FLAGS] if X holds a NaN/Inf (stats may be NULL).          */
+int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
+                    float* Xp, int64_t ldp, int32_t* stats, fsw_stream_t stream);
+
+/* ---- unit-weight readout coefficients ------------------------------------------------------------
+ * table[(D*(D-1)/2 + t) * ldt + k] = (1+xi_k) * [sin(2 pi xi_k (t+1)/D) - sin(2 pi xi_k t/D)] / (pi xi_k)
+ * for 1 <= D <= max_deg, 0 <= t < D (the reference's Delta_t of fsw_embedding.py:1047-1075 times the
+ * (1+xi) of :1109 for weights 1/D), evaluated in float64 and rounded once.                        */
+size_t fsw_unit_table_rows(int max_deg);
+int fsw_unit_coeff_table(const float* freqs, int S, int max_deg, float* table, int64_t ldt, fsw_stream_t stream);
+
+/* ---- fused neighbourhood sort + segmented cumsum + Fourier readout --------------------------------
+ * Replaces forward_helper's sparse branch (reference fsw_embedding.py:917-1112) and the epilogue
+ * (:853-888) for the 'plain' total-mass method.  For every row r and slice k:
+ *   out[r*ldo + has_mass + k] = out_scale * ( (1+xi_k) * sum_t Delta_t p_(t) + bias[has_mass + k] )
+ *   out[r*ldo]                = out_scale * ( f(m_r) * mass_scale + bias[0] )        if has_mass     */
+typedef struct {
+  /* adjacency (from fsw_graph_build) */
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* w; /* NULL = unit weights */
+  const int32_t* perm;
+  const int32_t* bin_start;
+  int64_t num_rows;
+  /* projected features and slice parameters */
+  const float* Xp;
+  int64_t ldp;
+  const float* freqs; /* [S] */
+  int32_t S;
+  float tau;                 /* total_mass_pad_thresh */
+  const float* unit_table;   /* from fsw_unit_coeff_table, required when w == NULL and tau <= 1 */
+  int64_t ldt;
+  /* output */
+  float* out;
+  int64_t ldo;
+  const float* bias; /* NULL or [has_mass + S] */
+  float out_scale;
+  int32_t has_mass;  /* 1: column 0 of out carries the encoded total mass */
+  int32_t mass_fn;   /* 0 identity, 1 sqrt: 2m/(sqrt(m+1)+1), 2 log1p      (fsw_embedding.py:857-865) */
+  float mass_scale;
+  /* row counts per path, host values read back from stats; -1 = unknown (launch every path) */
+  int64_t num_reg_rows, num_lds_rows, num_global_rows, num_zero_rows;
+  int64_t max_degree; /* host value of stats[FSW_STAT_MAX_DEGREE]; required when num_global_rows != 0 */
+  /* scratch for the global path: >= fsw_embed_scratch_bytes() or NULL if num_global_rows == 0 */
+  void* scratch;
+  size_t scratch_bytes;
+} fsw_embed_args;
+
+size_t fsw_embed_scratch_bytes(int64_t max_degree);
+int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
+
+/* ---- stand-alone segmented cumulative sum --------------------------------------------------------
+ * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of
+ * values restarted wherever consecutive segment ids differ, single pass (decoupled look-back),
+ * in place allowed (out == values).  value_dtype: 0 float32, 1 float64 (the reference's torch_dtype
+ * enum, fsw_embedding.cu:14-17).  id_bytes: 4 or 8.  reverse != 0 scans from the end (the backward
+ * pass of cumsum_sparse, fsw_embedding.py:2158-2172).  workspace: fsw_segcumsum_workspace_bytes(n). */
+size_t fsw_segcumsum_workspace_bytes(int64_t n);
+int fsw_segcumsum(int value_dtype, const void* values, void* out, const void* segment_ids, int id_bytes,
+                  int64_t n, int reverse, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
+
+/* ---- legacy entry points: exact signatures of reference fsw_embedding.cu:194, 212, 231 ------------
+ * Same semantics as the reference kernels (block-local segmented scan + carry add), launched on the
+ * default stream with a stream synchronise after the launch, void return.                           */
+void segcumsum_wrapper(int dtype, void* values, const int64_t* segment_ids, int64_t size, int64_t max_seg_size,
+                       void* block_sums_out, int64_t* block_last_ids_out, bool return_next_level, int64_t num_blocks,
+                       int64_t threads_per_block, size_t shared_memory_size);
+void add_block_sums_wrapper(int dtype, void* output, const void* block_sums, const int64_t* segment_ids,
+                            const int64_t* block_last_id, int64_t size, int64_t num_blocks, int64_t threads_per_block);
+int get_max_threads_per_block(int device_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSW_HIP_H */

@@ -1,0 +1,356 @@
+"""GPU parity tests: the HIP path (through the C ABI of libfsw_hip.so) against golden vectors captured from
+the reference's CPU path and against the CPU oracle on the same seeded inputs.
+
+Tolerance: the north star asks for 1e-5 relative in float32.  As SURVEY.md 8(c) records, the reference's own
+float32 output differs from its float64 output by ~5e-6 norm-wise at S=256 'spread' frequencies, so the
+criterion is norm-wise relative error <= 1e-5 against the float64 golden (TOL below).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as C
+from oracle import fsw_oracle as O
+from tests import cases
+from tests.conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def t(a, dev, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dtype)
+
+
+def make_embedding(dev, V, freqs, bias=None, scale=None, **kw):
+    from fsw_gnn_amd import FSW_embedding
+    S, d = V.shape
+    encode = kw.get("encode_total_mass", False)
+    E = FSW_embedding(d_in=d, d_out=S + (1 if encode else 0), device=dev, **kw)
+    with torch.no_grad():
+        E.projVecs.copy_(t(V, dev))
+        E.freqs.copy_(t(freqs, dev))
+        if bias is not None and E.enable_bias:
+            E.bias.copy_(t(bias, dev))
+        if scale is not None:
+            E.total_mass_encoding_scale.fill_(scale)
+    return E
+
+
+def sparse_adj(idx, vals, shape, dev):
+    return torch.sparse_coo_tensor(torch.from_numpy(idx).to(dev), t(vals, dev), shape).coalesce()
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_projection_mfma_vs_float64(dev):
+    from fsw_gnn_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for n, d, S in ((1000, 64, 32), (777, 13, 70), (4096, 128, 256), (130, 3, 129)):
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        V = rng.standard_normal((S, d)).astype(np.float32)
+        Xd, Vd = t(X, dev), t(V, dev)
+        ldp = (S + 63) // 64 * 64
+        Xp = torch.full((n, ldp), float("nan"), device=dev)
+        stats = torch.zeros(8, dtype=torch.int32, device=dev)
+        rc = L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, stats.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = X.astype(np.float64) @ V.astype(np.float64).T
+        assert relerr(Xp[:, :S].cpu().numpy(), ref) < 2e-7
+        assert int(stats[0]) == 0
+    Xd[5, 1] = float("inf")
+    L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, stats.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    assert int(stats[0]) & _lib.FLAG_X_NONFINITE
+
+
+def test_graph_build_matches_oracle_adjacency(dev):
+    from fsw_gnn_amd import build_csr
+    g = golden("tiny_graph")
+    ei = g["edge_index"]
+    gr = build_csr(t(ei[1], dev, torch.int64), t(ei[0], dev, torch.int64), None, 64, 64)
+    rowptr = gr.rowptr.cpu().numpy()
+    col = gr.col.cpu().numpy()
+    deg_ref = np.bincount(ei[1], minlength=64)
+    assert np.array_equal(np.diff(rowptr), deg_ref)
+    for r in range(64):                                   # same multiset of senders per recipient
+        assert sorted(col[rowptr[r]:rowptr[r + 1]]) == sorted(ei[0][ei[1] == r])
+    perm = gr.perm.cpu().numpy()
+    bins = gr.bin_start.cpu().numpy()
+    assert sorted(perm) == list(range(64))
+    for b in range(len(bins) - 1):
+        for r in perm[bins[b]:bins[b + 1]]:
+            assert min(deg_ref[r], 33) == b or (deg_ref[r] > 2048 and b == 34)
+    assert gr.max_degree == deg_ref.max() and gr.stats()[2] == (deg_ref == 0).sum()
+    # out-of-range endpoints are flagged, not dereferenced
+    bad = ei.copy()
+    bad[0, 3] = 64
+    gr2 = build_csr(t(bad[1], dev, torch.int64), t(bad[0], dev, torch.int64), None, 64, 64)
+    assert gr2.flags & 1
+
+
+def test_tiny_graph_all_variants(dev):
+    g = golden("tiny_graph")
+    X = t(g["X"], dev)
+    adj = sparse_adj(g["adj_indices"], g["adj_values"], (64, 64), dev)
+    with torch.no_grad():
+        E = make_embedding(dev, g["V"], g["freqs"], enable_bias=False)
+        out = E(X, adj, graph_mode=True).cpu().numpy()
+        assert relerr(out, g["out_plain_nomass_nobias"]) < TOL
+        assert np.abs(out[56:]).max() == 0.0                                  # isolated recipients
+        for fn in ("identity", "sqrt", "log"):
+            for method in ("plain", "homog", "homog_alt"):
+                E = make_embedding(dev, g["V"], g["freqs"], bias=g["bias"], scale=0.7, encode_total_mass=True,
+                                   total_mass_encoding_function=fn, total_mass_encoding_method=method,
+                                   total_mass_encoding_scale=0.7)
+                got = E(X, adj, graph_mode=True).cpu().numpy()
+                assert relerr(got, g["out_%s_%s" % (fn, method)]) < TOL, (fn, method)
+        E = make_embedding(dev, g["V"], g["freqs"], enable_bias=False, total_mass_pad_thresh=3.0)
+        assert relerr(E(X, adj, graph_mode=True).cpu().numpy(), g["out_tau3"]) < TOL
+        E = make_embedding(dev, g["V"], g["freqs"], enable_bias=False)
+        adj2 = sparse_adj(g["adj2_indices"], g["adj2_values"], (64, 64), dev)
+        assert relerr(E(X, adj2, graph_mode=True).cpu().numpy(), g["out_gcn_selfloop"]) < TOL
+        adj3 = sparse_adj(g["adj_indices"], g["adj3_values"], (64, 64), dev)
+        assert relerr(E(X, adj3, graph_mode=True).cpu().numpy(), g["out_weighted"]) < TOL
+        assert relerr(E(X, adj3.to_dense(), graph_mode=True).cpu().numpy(), g["out_weighted"]) < TOL   # dense W
+        E = make_embedding(dev, g["V"], g["freqs"], bias=g["bias"], scale=0.7, encode_total_mass=True,
+                           total_mass_encoding_scale=0.7)
+        assert relerr(E(X, adj3, graph_mode=True).cpu().numpy(), g["out_weighted_mass"]) < TOL
+        # serialize_num_slices changes nothing (property 2)
+        a = E(X, adj3, graph_mode=True)
+        b = E(X, adj3, graph_mode=True, serialize_num_slices=5)
+        assert torch.equal(a, b)
+
+
+def test_conv_layer_gcn_selfloops_matches_reference_adjacency(dev):
+    """FSW_conv.build_graph with self loops + 'gcn' weighting == the reference's coalesced adjacency."""
+    from fsw_gnn_amd import FSW_conv
+    g = golden("tiny_graph")
+    conv = FSW_conv(8, 4, embed_dim=16, encode_vertex_degrees=False, mlp_layers=0, concat_self=False, bias=False,
+                    self_loop_weight=0.5, edge_weighting="gcn", device=dev)
+    with torch.no_grad():
+        conv.fsw_embed.projVecs.copy_(t(g["V"], dev))
+        conv.fsw_embed.freqs.copy_(t(g["freqs"], dev))
+        out = conv(t(g["X"], dev), t(g["edge_index"], dev, torch.int64)).cpu().numpy()
+    assert relerr(out, g["out_gcn_selfloop"]) < TOL
+
+
+def test_pointcloud_config1_and_batches(dev):
+    g = golden("pointcloud_1k")
+    c = cases.pointcloud_1k()
+    with torch.no_grad():
+        E = make_embedding(dev, c["V"], c["freqs"])
+        out = E(t(c["X"], dev)).cpu().numpy()
+    assert out.shape == (32,)
+    assert relerr(out, g["out_f64"]) < TOL
+    gb = golden("pointcloud_batch")
+    with torch.no_grad():
+        E = make_embedding(dev, gb["V"], gb["freqs"], bias=gb["bias"])
+        out = E(t(gb["X"], dev), t(gb["W"], dev)).cpu().numpy()
+        outu = E(t(gb["X"], dev), "uniform").cpu().numpy()
+        # graph mode == expanded non-graph mode (reference docstring fsw_embedding.py:603-605)
+        Wg = t(gb["W"], dev)
+        outg = E(t(gb["X"][0], dev), Wg[0:1].expand(3, -1).contiguous() * 1.0, graph_mode=True).cpu().numpy()
+    assert relerr(out, gb["out_f64"]) < TOL
+    assert relerr(outu, gb["out_f64_uniform"]) < TOL
+    assert relerr(outg[0], gb["out_f64"][0]) < TOL
+
+
+def _conv_from_case(c, dev):
+    from fsw_gnn_amd import FSW_conv
+    conv = FSW_conv(c["d"], c["out_ch"], embed_dim=c["embed_dim"], device=dev)
+    with torch.no_grad():
+        conv.fsw_embed.projVecs.copy_(t(c["V"], dev))
+        conv.fsw_embed.freqs.copy_(t(c["freqs"], dev))
+        conv.mlp[0].weight.copy_(t(c["lin_w"], dev))
+        conv.mlp[0].bias.copy_(t(c["lin_b"], dev))
+    return conv
+
+
+def test_conv10k_config2(dev):
+    g = golden("conv10k")
+    c = cases.conv10k()
+    conv = _conv_from_case(c, dev)
+    X, ei = t(c["X"], dev), t(c["edge_index"], dev, torch.int64)
+    with torch.no_grad():
+        y = conv(X, ei)
+        graph = conv.build_graph(ei, c["n"])
+        emb = torch.empty((c["n"], c["embed_dim"]), device=dev)
+        conv.fsw_embed.embed_into(X, graph, emb)
+    rows = g["rows"]
+    emb = emb.cpu().numpy()
+    assert relerr(emb[rows], g["emb_rows_f64"]) < TOL
+    assert relerr(np.linalg.norm(emb.astype(np.float64), axis=0), g["emb_colnorm_f64"]) < TOL
+    assert np.array_equal(emb[:, 0], g["in_degrees"])                       # degree column is exact
+    y = y.cpu().numpy()
+    assert relerr(y[rows], g["conv_rows_f64"]) < 2e-5                        # + one fp32 GEMM (stock torch)
+    # not worse than the reference's own float32 path measured against its float64 path
+    assert relerr(emb[rows], g["emb_rows_f64"]) <= 1.5 * relerr(g["emb_rows_f32"], g["emb_rows_f64"]) + 1e-6
+
+
+def test_rmat14_long_rows_lds_and_global_paths(dev):
+    g = golden("rmat14")
+    c = cases.rmat(14)
+    E = make_embedding(dev, c["V"], c["freqs"], encode_total_mass=True, enable_bias=False)
+    from fsw_gnn_amd import build_csr
+    ei = t(c["edge_index"], dev, torch.int64)
+    with torch.no_grad():
+        graph = build_csr(ei[1].contiguous(), ei[0].contiguous(), None, c["n"], c["n"])
+        emb = torch.empty((c["n"], c["S"] + 1), device=dev)
+        E.embed_into(t(c["X"], dev), graph, emb)
+    st = graph.stats()
+    assert st[4] > 0, "expected rows on the LDS path"
+    emb = emb.cpu().numpy()
+    assert relerr(emb[g["rows"]], g["emb_rows_f64"]) < TOL
+    assert relerr(np.linalg.norm(emb.astype(np.float64), axis=0), g["emb_colnorm_f64"]) < TOL
+
+
+def test_long_rows_weighted_and_global_scratch_path(dev):
+    """Few very long neighbourhoods (FSW_readout shape): 3 graphs of 700 / 3000 / 5000 vertices, weighted and unit."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(3)
+    sizes = [700, 3000, 5000]
+    n, d, S = sum(sizes), 16, 24
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=81)
+    fr = cases.random_freqs(S, seed=82)
+    gi = np.repeat(np.arange(3), sizes).astype(np.int64)
+    w = (rng.random(n) + 0.1).astype(np.float32)
+    w[gi == 0] *= 0.5 / w[gi == 0].sum()                        # first graph: total mass 0.5 < tau -> pad element
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    col = np.arange(n)
+    for weights in (None, w):
+        E = make_embedding(dev, V, fr, enable_bias=False)
+        with torch.no_grad():
+            graph = build_csr(t(gi, dev, torch.int64), t(col, dev, torch.int64), None if weights is None else t(weights, dev), 3, n)
+            out = torch.empty((3, S), device=dev)
+            E.embed_into(t(X, dev), graph, out)
+        assert graph.stats()[5] == 2 and graph.stats()[4] == 1                # two global-path rows, one LDS row
+        ref = C.embed(X, rowptr, col, weights, V, fr)
+        assert relerr(out.cpu().numpy(), ref) < TOL
+
+
+def test_readout_layer(dev):
+    from fsw_gnn_amd import FSW_readout
+    rng = np.random.default_rng(4)
+    sizes = [40, 1, 300, 0, 77]                                  # includes an empty graph
+    n, d = sum(sizes), 8
+    gi = np.repeat(np.arange(5), sizes).astype(np.int64)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    ro = FSW_readout(d, 6, embed_dim=20, concat_self=False, mlp_layers=0, bias=False, device=dev)
+    with torch.no_grad():
+        out = ro(t(X, dev), t(gi, dev, torch.int64), 5).cpu().numpy()
+    V = ro.fsw_embed.projVecs.detach().cpu().numpy()
+    fr = ro.fsw_embed.freqs.detach().cpu().numpy()
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    ref = O.fsw_embedding_forward(X, rowptr, np.arange(n), np.ones(n), V, fr, encode_total_mass=True)
+    assert out.shape == (5, 20)
+    assert relerr(out, ref) < TOL
+    assert np.abs(out[3]).max() == 0.0
+
+
+def test_er1m_config3_full_size(dev):
+    """BASELINE config 3 at full size against rows sampled from the reference's float64 run."""
+    g = golden("er1m")
+    c = cases.er1m()
+    conv = _conv_from_case(c, dev)
+    X, ei = t(c["X"], dev), t(c["edge_index"], dev, torch.int64)
+    with torch.no_grad():
+        graph = conv.build_graph(ei, c["n"])
+        emb = torch.empty((c["n"], c["embed_dim"]), device=dev)
+        conv.fsw_embed.embed_into(X, graph, emb)
+        y = conv(X, ei)
+        torch.cuda.synchronize()
+    st = graph.stats()
+    assert st[2] == int(g["num_zero_degree"]) and st[1] >= int(g["max_degree"])
+    rows = g["rows"]
+    er = emb[t(rows, dev, torch.int64)].cpu().numpy()
+    assert relerr(er, g["emb_rows_f64"]) < TOL
+    coln = torch.linalg.vector_norm(emb.double(), dim=0).cpu().numpy()
+    assert relerr(coln, g["emb_colnorm_f64"]) < TOL
+    assert abs(float(torch.linalg.vector_norm(emb.double())) - float(g["emb_norm_f64"])) / float(g["emb_norm_f64"]) < TOL
+    zero_rows = rows[np.abs(g["emb_rows_f64"]).max(axis=1) == 0]
+    assert zero_rows.size == int(g["num_zero_degree"])
+    assert float(emb[t(zero_rows, dev, torch.int64)].abs().max()) == 0.0
+    # conv tail on the sampled rows through the oracle's restatement of fsw_conv.py:357-362
+    ref_y = O.conv_tail(g["emb_rows_f64"], c["X"][rows].astype(np.float64), linear_weight=c["lin_w"], linear_bias=c["lin_b"])
+    assert relerr(y[t(rows, dev, torch.int64)].cpu().numpy(), ref_y) < 2e-5
+    # size-independent properties at full size: positive homogeneity and edge-order invariance
+    with torch.no_grad():
+        emb2 = torch.empty_like(emb)
+        conv.fsw_embed.embed_into(X * 4.0, graph, emb2)
+        assert relerr((emb2[:, 1:] / 4.0).cpu().numpy()[::97], emb[:, 1:].cpu().numpy()[::97]) < 1e-6
+        perm = torch.randperm(ei.shape[1], device=dev)
+        graph3 = conv.build_graph(ei[:, perm].contiguous(), c["n"])
+        emb3 = torch.empty_like(emb)
+        conv.fsw_embed.embed_into(X, graph3, emb3)
+        assert torch.equal(emb3, emb)                     # unit path: bitwise independent of the edge order
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_segcumsum_golden_and_reverse(dev):
+    from fsw_gnn_amd import segcumsum
+    g = golden("segcumsum")
+    ids = g["ids"]
+    for tag, dt, tol in (("f32", torch.float32, 2e-6), ("f64", torch.float64, 1e-14)):
+        v = t(g["values_" + tag], dev, dt)
+        for idt in (torch.int64, torch.int32):
+            got = segcumsum(v, t(ids, dev, idt))
+            assert relerr(got.cpu().numpy(), g["slow_" + tag]) < tol
+            assert relerr(got.cpu().numpy(), g["out_" + tag]) < max(tol, 1e-5 if tag == "f32" else tol)
+        rev = segcumsum(v, t(ids, dev, torch.int64), reverse=True).cpu().numpy()
+        ref = O.segcumsum(g["values_" + tag][::-1].copy(), ids[::-1].copy())[::-1]
+        assert relerr(rev, ref) < tol
+        vc = v.clone()
+        same = segcumsum(vc, t(ids, dev, torch.int64), in_place=True)
+        assert same.data_ptr() == vc.data_ptr() and relerr(vc.cpu().numpy(), g["slow_" + tag]) < tol
+
+
+def test_segcumsum_large_random(dev):
+    from fsw_gnn_amd import segcumsum
+    rng = np.random.default_rng(7)
+    n = 3_000_017
+    lens = rng.integers(1, 40, size=n // 10)
+    lens[100] = 50_000                                      # spans many tiles
+    ids = np.repeat(np.arange(lens.size), lens)[:n]
+    vals = rng.standard_normal(ids.size)
+    got = segcumsum(t(vals, dev, torch.float64), t(ids, dev, torch.int64)).cpu().numpy()
+    assert relerr(got, O.segcumsum(vals, ids)) < 1e-13
+
+
+def test_legacy_abi_drives_reference_hierarchy(dev):
+    """segcumsum_wrapper / add_block_sums_wrapper with the reference's driver loop (fsw_embedding.py:2905-3010)."""
+    import ctypes
+    from fsw_gnn_amd import _lib
+    L = _lib.lib()
+    g = golden("segcumsum")
+    ids = t(g["ids"], dev, torch.int64)
+    for tag, dt, dnum in (("f32", torch.float32, 0), ("f64", torch.float64, 1)):
+        vals = t(g["values_" + tag], dev, dt)
+        tpb = 256
+        sizes, max_seg = [vals.numel()], [1300]
+        while sizes[-1] > tpb:
+            sizes.append((sizes[-1] + tpb - 1) // tpb)
+            max_seg.append((max_seg[-1] + tpb - 1) // tpb)
+        nblocks = sizes[1:] + [1]
+        outs = [vals.clone()] + [torch.empty(s, device=dev, dtype=dt) for s in sizes[1:]]
+        idts = [ids] + [torch.empty(s, device=dev, dtype=torch.int64) for s in sizes[1:]]
+        torch.cuda.synchronize()
+        for i, s in enumerate(sizes):
+            nxt = i < len(sizes) - 1
+            L.segcumsum_wrapper(dnum, outs[i].data_ptr(), idts[i].data_ptr(), s, max_seg[i],
+                                outs[i + 1].data_ptr() if nxt else None, idts[i + 1].data_ptr() if nxt else None,
+                                nxt, nblocks[i], tpb, tpb * vals.element_size())
+        for i in reversed(range(len(sizes) - 1)):
+            L.add_block_sums_wrapper(dnum, outs[i].data_ptr(), outs[i + 1].data_ptr(), idts[i].data_ptr(),
+                                     idts[i + 1].data_ptr(), sizes[i], nblocks[i], tpb)
+        assert relerr(outs[0].cpu().numpy(), g["slow_" + tag]) < (2e-6 if tag == "f32" else 1e-14)
+    assert L.get_max_threads_per_block(0) == 1024
