@@ -64,7 +64,7 @@ def test_projection_mfma_vs_float64(dev):
                                torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         ref = X.astype(np.float64) @ V.astype(np.float64).T
-        assert relerr(Xp[:, :S].cpu().numpy(), ref) < 2e-7
+        assert relerr(Xp[:, :S].cpu().numpy(), ref) < 5e-7      # fp32 fma chain over d terms
         assert int(stats[0]) == 0
     Xd[5, 1] = float("inf")
     L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, stats.data_ptr(),
@@ -134,7 +134,7 @@ def test_conv_layer_gcn_selfloops_matches_reference_adjacency(dev):
     """FSW_conv.build_graph with self loops + 'gcn' weighting == the reference's coalesced adjacency."""
     from fsw_gnn_amd import FSW_conv
     g = golden("tiny_graph")
-    conv = FSW_conv(8, 4, embed_dim=16, encode_vertex_degrees=False, mlp_layers=0, concat_self=False, bias=False,
+    conv = FSW_conv(8, 16, encode_vertex_degrees=False, mlp_layers=0, concat_self=False, bias=False,
                     self_loop_weight=0.5, edge_weighting="gcn", device=dev)
     with torch.no_grad():
         conv.fsw_embed.projVecs.copy_(t(g["V"], dev))
@@ -245,7 +245,7 @@ def test_readout_layer(dev):
     n, d = sum(sizes), 8
     gi = np.repeat(np.arange(5), sizes).astype(np.int64)
     X = rng.standard_normal((n, d)).astype(np.float32)
-    ro = FSW_readout(d, 6, embed_dim=20, concat_self=False, mlp_layers=0, bias=False, device=dev)
+    ro = FSW_readout(d, 20, concat_self=False, mlp_layers=0, bias=False, device=dev)   # embed_dim = out_channels (fsw_conv.py:228-229)
     with torch.no_grad():
         out = ro(t(X, dev), t(gi, dev, torch.int64), 5).cpu().numpy()
     V = ro.fsw_embed.projVecs.detach().cpu().numpy()
