@@ -1,12 +1,19 @@
 // Edge list -> CSR by recipient + degree bins.  gfx950.
 //
 // Replaces FSW_conv.edge_index_to_adj (reference fsw_conv.py:384-447) and the sp.get_slice_info sorts of
-// FSW_embedding.forward (reference fsw_embedding.py:778-821).  The reference sorts E int64 COO keys
-// (coalesce + stable sort); here the adjacency is grouped by recipient with a counting sort:
-//   histogram of recipients (int atomics on an L2-resident counter array) -> exclusive scan -> scatter
-// and the rows are then bucketed by in-degree so the fused neighbourhood kernels can run exact-size
-// sorting networks on runs of equal-degree rows.  All passes are coalesced streams over the edge list
-// (16 B/edge read twice, 4-8 B/edge written once).
+// FSW_embedding.forward (reference fsw_embedding.py:778-821).  The reference coalesces and stable-sorts E
+// int64 COO keys with torch.sort; here the edges are grouped by recipient with a hand-written stable LSD
+// radix sort on the recipient index only (ceil(log2(rows+1)) bits, 7-8 bits per pass):
+//   upsweep    per 4096-edge tile: digit histogram (wave-aggregated LDS atomics)
+//   scan       exclusive scan of the digit-major [digit][tile] count table = global base of every (tile, digit)
+//   downsweep  wave64 match ranking (ballot per digit bit), per-wave digit counters in LDS, tile-local
+//              reorder through LDS so the global writes are runs of consecutive addresses per digit
+// The first pass reads the int64 edge_index directly (and validates it), later passes move int32 pairs.
+// The sort is stable, so every CSR row keeps its senders in edge-list order: the build is deterministic.
+// rowptr comes from the boundaries of the sorted keys; rows are then bucketed by in-degree so the fused
+// neighbourhood kernels run exact-size sorting networks on runs of equal-degree rows.
+// (A first version used one global int atomic per edge for the histogram and one for the scatter:
+//  1.13 ms at 10M edges against ~0.3 ms for the sort -- profiles/r01_v1_bench_kernel_stats.csv.)
 #include <algorithm>
 #include "fsw_common.h"
 
@@ -14,55 +21,17 @@ namespace fsw {
 
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 16;
-constexpr int kScanTile = kScanThreads * kScanItems;  // rows per scan block
+constexpr int kScanTile = kScanThreads * kScanItems;
 
-struct GraphWs {
-  int32_t* cursor;      // [num_rows + 1] degree counters, then running insertion cursors
-  int32_t* block_sums;  // [num_scan_blocks]
-  int32_t* bin_count;   // [FSW_NUM_BINS]
-  int32_t* bin_cursor;  // [FSW_NUM_BINS]
-};
+constexpr int kRsThreads = 256;
+constexpr int kRsItems = 16;                      // rounds of 64 consecutive edges per wave
+constexpr int kRsTile = kRsThreads * kRsItems;    // 4096 edges per tile
+constexpr int kRsWaves = kRsThreads / kWave;
+constexpr int kRsMaxDigits = 256;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static GraphWs carve(void* ws, int64_t num_rows) {
-  char* p = reinterpret_cast<char*>(ws);
-  GraphWs g;
-  g.cursor = reinterpret_cast<int32_t*>(p);
-  p += align_up(sizeof(int32_t) * (size_t)(num_rows + 1), 256);
-  g.block_sums = reinterpret_cast<int32_t*>(p);
-  p += align_up(sizeof(int32_t) * (size_t)(ceil_div(num_rows, kScanTile) + 1), 256);
-  g.bin_count = reinterpret_cast<int32_t*>(p);
-  p += 256;
-  g.bin_cursor = reinterpret_cast<int32_t*>(p);
-  return g;
-}
-
-// ---- pass 1: in-degree histogram + input validation --------------------------------------------
-__global__ void __launch_bounds__(256) k_degree_hist(const int64_t* __restrict__ recipients,
-                                                     const int64_t* __restrict__ senders,
-                                                     const float* __restrict__ edge_w, int64_t num_edges,
-                                                     int64_t num_rows, int64_t num_cols, int32_t* __restrict__ cnt,
-                                                     int32_t* __restrict__ stats) {
-  int flags = 0;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges; e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = recipients[e];
-    int64_t c = senders[e];
-    if (r < 0 || r >= num_rows || c < 0 || c >= num_cols) {
-      flags |= FSW_FLAG_INDEX_RANGE;
-      continue;
-    }
-    if (edge_w) {
-      float w = edge_w[e];
-      if (!(fabsf(w) <= 3.402823466e38f)) flags |= FSW_FLAG_W_NONFINITE;  // NaN or Inf
-      if (w < 0.f) flags |= FSW_FLAG_W_NEGATIVE;
-    }
-    atomicAdd(&cnt[r], 1);
-  }
-  if (flags) atomicOr(&stats[FSW_STAT_FLAGS], flags);
-}
-
-// ---- pass 2: exclusive scan of the degrees (3 small kernels) -------------------------------------
+// ---- generic device-wide exclusive scan of int32 (three launches) ----------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
@@ -72,7 +41,6 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
-// exclusive scan of one int per thread across a 256-thread block; returns exclusive prefix, total in *total
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
   __shared__ int wsum[kScanThreads / kWave];
   int inc = wave_inclusive_scan(v);
@@ -91,13 +59,13 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
   return base + inc - v;
 }
 
-__global__ void __launch_bounds__(kScanThreads) k_scan_partial(const int32_t* __restrict__ cnt, int64_t n,
+__global__ void __launch_bounds__(kScanThreads) k_scan_partial(const int32_t* __restrict__ in, int64_t n,
                                                                int32_t* __restrict__ block_sums) {
   int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   int s = 0;
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i)
-    if (base + i < n) s += cnt[base + i];
+    if (base + i < n) s += in[base + i];
   int tot;
   block_exclusive_scan(s, &tot);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
@@ -115,37 +83,242 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_block_sums(int32_t* __res
   }
 }
 
-// final pass: rowptr, insertion cursors, degree-bin histogram, max degree
-__global__ void __launch_bounds__(kScanThreads) k_scan_final(int32_t* __restrict__ cursor /* in: degrees, out: row starts */,
-                                                             int64_t n, const int32_t* __restrict__ block_sums,
-                                                             int32_t* __restrict__ rowptr, int32_t* __restrict__ bin_count,
-                                                             int32_t* __restrict__ stats) {
-  __shared__ int lbin[FSW_NUM_BINS];
-  __shared__ int lmax;
-  if (threadIdx.x < FSW_NUM_BINS) lbin[threadIdx.x] = 0;
-  if (threadIdx.x == 0) lmax = 0;
-  __syncthreads();
+__global__ void __launch_bounds__(kScanThreads) k_scan_apply(int32_t* __restrict__ data, int64_t n,
+                                                             const int32_t* __restrict__ block_sums) {
   int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-  int deg[kScanItems];
-  int s = 0, mx = 0;
+  int v[kScanItems];
+  int s = 0;
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i) {
-    deg[i] = base + i < n ? cursor[base + i] : 0;
-    s += deg[i];
-    mx = max(mx, deg[i]);
+    v[i] = base + i < n ? data[base + i] : 0;
+    s += v[i];
   }
   int tot;
   int ex = block_exclusive_scan(s, &tot) + block_sums[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) {
-      rowptr[base + i] = ex;
-      cursor[base + i] = ex;
-      atomicAdd(&lbin[degree_bin(deg[i])], 1);
-      ex += deg[i];
+    if (base + i < n) data[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+static int exclusive_scan_i32(int32_t* data, int64_t n, int32_t* block_sums, hipStream_t stream) {
+  const int64_t nb = ceil_div(n, kScanTile);
+  k_scan_partial<<<(unsigned)nb, kScanThreads, 0, stream>>>(data, n, block_sums);
+  FSW_LAUNCH_CHECK();
+  k_scan_block_sums<<<1, kScanThreads, 0, stream>>>(block_sums, nb);
+  FSW_LAUNCH_CHECK();
+  k_scan_apply<<<(unsigned)nb, kScanThreads, 0, stream>>>(data, n, block_sums);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- radix sort by recipient ----------------------------------------------------------------------------
+// Key of edge e: its recipient, or `num_rows` (a sentinel that sorts last) when an endpoint is out of range.
+template <bool FIRST>
+__device__ __forceinline__ uint32_t load_key(const int64_t* __restrict__ recipients, const int64_t* __restrict__ senders,
+                                             const uint32_t* __restrict__ keys_in, int64_t e, int64_t num_rows,
+                                             int64_t num_cols, int& flags) {
+  if constexpr (FIRST) {
+    const int64_t r = recipients[e], c = senders[e];
+    if (r < 0 || r >= num_rows || c < 0 || c >= num_cols) {
+      flags |= FSW_FLAG_INDEX_RANGE;
+      return (uint32_t)num_rows;
+    }
+    return (uint32_t)r;
+  } else {
+    return keys_in[e];
+  }
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(kRsThreads) k_rs_upsweep(const int64_t* __restrict__ recipients,
+                                                           const int64_t* __restrict__ senders,
+                                                           const float* __restrict__ edge_w,
+                                                           const uint32_t* __restrict__ keys_in, int64_t num_edges,
+                                                           int64_t num_rows, int64_t num_cols, int shift, int ndigits,
+                                                           int32_t* __restrict__ counts /* [ndigits][ntiles] */, int64_t ntiles,
+                                                           int32_t* __restrict__ stats) {
+  __shared__ int hist[kRsMaxDigits];
+  for (int d = threadIdx.x; d < ndigits; d += kRsThreads) hist[d] = 0;
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kRsTile;
+  const uint32_t mask = (uint32_t)ndigits - 1;
+  int flags = 0;
+#pragma unroll 4
+  for (int i = 0; i < kRsItems; ++i) {
+    const int64_t e = tile0 + (int64_t)i * kRsThreads + threadIdx.x;
+    if (e < num_edges) {
+      const uint32_t key = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, flags);
+      if (FIRST && edge_w) {
+        const float w = edge_w[e];
+        if (!(fabsf(w) <= 3.402823466e38f)) flags |= FSW_FLAG_W_NONFINITE;
+        if (w < 0.f) flags |= FSW_FLAG_W_NEGATIVE;
+      }
+      atomicAdd(&hist[(key >> shift) & mask], 1);
     }
   }
-  if (base <= n - 1 && base + kScanItems > n - 1) rowptr[n] = ex;  // the thread owning the last row
+  __syncthreads();
+  for (int d = threadIdx.x; d < ndigits; d += kRsThreads) counts[(int64_t)d * ntiles + blockIdx.x] = hist[d];
+  if (FIRST && flags) atomicOr(&stats[FSW_STAT_FLAGS], flags);
+}
+
+// VAL = uint32_t (sender) for unit weights, uint64_t (sender | weight bits << 32) when weights are carried
+template <bool FIRST, class VAL>
+__global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __restrict__ recipients,
+                                                             const int64_t* __restrict__ senders,
+                                                             const float* __restrict__ edge_w,
+                                                             const uint32_t* __restrict__ keys_in,
+                                                             const VAL* __restrict__ vals_in, int64_t num_edges,
+                                                             int64_t num_rows, int64_t num_cols, int shift, int nbits,
+                                                             const int32_t* __restrict__ bases /* scanned [ndigits][ntiles] */,
+                                                             int64_t ntiles, uint32_t* __restrict__ keys_out,
+                                                             VAL* __restrict__ vals_out) {
+  __shared__ int wcnt[kRsWaves][kRsMaxDigits];   // per-wave digit counters, then exclusive wave bases
+  __shared__ int dstart[kRsMaxDigits];           // tile-local exclusive start of each digit
+  __shared__ int gbase[kRsMaxDigits];            // global base of (this tile, digit)
+  __shared__ uint32_t skey[kRsTile];
+  __shared__ VAL sval[kRsTile];
+  const int ndigits = 1 << nbits;
+  const uint32_t mask = (uint32_t)ndigits - 1;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < ndigits; d += kRsThreads) {
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) wcnt[w][d] = 0;
+    gbase[d] = bases[(int64_t)d * ntiles + blockIdx.x];
+  }
+  __syncthreads();
+
+  // wave wv owns tile elements [wv*1024, wv*1024 + 1024) as 16 rounds of 64 consecutive edges (stable order)
+  const int64_t wave0 = (int64_t)blockIdx.x * kRsTile + (int64_t)wv * (kRsItems * kWave);
+  uint32_t key[kRsItems];
+  VAL val[kRsItems];
+  int rank[kRsItems];
+  int dummy = 0;
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const int64_t e = wave0 + (int64_t)i * kWave + lane;
+    const bool ok = e < num_edges;
+    key[i] = 0xffffffffu;
+    val[i] = VAL(0);
+    if (ok) {
+      key[i] = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, dummy);
+      if constexpr (FIRST) {
+        const uint32_t s = (uint32_t)senders[e];
+        if constexpr (sizeof(VAL) == 8)
+          val[i] = (VAL)s | ((VAL)__float_as_uint(edge_w[e]) << 32);
+        else
+          val[i] = (VAL)s;
+      } else {
+        val[i] = vals_in[e];
+      }
+    }
+    // match: lanes of this round with the same digit (inactive tail lanes form their own group, never stored)
+    const uint32_t d = ok ? ((key[i] >> shift) & mask) : (uint32_t)ndigits;
+    unsigned long long peers = __ballot(ok) ;
+    if (!ok) peers = ~peers;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b < nbits) {
+        const unsigned long long bb = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? bb : ~bb;
+      }
+    }
+    const int leader = __ffsll((long long)peers) - 1;
+    const int below = __popcll(peers & ((1ull << lane) - 1ull));
+    int prev = 0;
+    if (ok && lane == leader) {
+      prev = wcnt[wv][d];
+      wcnt[wv][d] = prev + __popcll(peers);
+    }
+    prev = __shfl(prev, leader);
+    rank[i] = prev + below;
+  }
+  __syncthreads();
+  // per digit: exclusive bases across waves and the tile-local digit start
+  for (int d = threadIdx.x; d < ndigits; d += kRsThreads) {
+    int acc = 0;
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) {
+      const int c = wcnt[w][d];
+      wcnt[w][d] = acc;
+      acc += c;
+    }
+    dstart[d] = acc;  // tile total for now
+  }
+  __syncthreads();
+  if (threadIdx.x < kWave) {  // exclusive scan of the tile totals over the digits (<= 256 = 4 per lane)
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = lane * 4 + j;
+      v[j] = d < ndigits ? dstart[d] : 0;
+      s += v[j];
+    }
+    int ex = wave_inclusive_scan(s) - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = lane * 4 + j;
+      if (d < ndigits) dstart[d] = ex;
+      ex += v[j];
+    }
+  }
+  __syncthreads();
+  // tile-local reorder through LDS
+#pragma unroll
+  for (int i = 0; i < kRsItems; ++i) {
+    const int64_t e = wave0 + (int64_t)i * kWave + lane;
+    if (e < num_edges) {
+      const uint32_t d = (key[i] >> shift) & mask;
+      const int lpos = dstart[d] + wcnt[wv][d] + rank[i];
+      skey[lpos] = key[i];
+      sval[lpos] = val[i];
+    }
+  }
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kRsTile;
+  const int count = (int)min((int64_t)kRsTile, num_edges - tile0);
+  for (int i = threadIdx.x; i < count; i += kRsThreads) {
+    const uint32_t k = skey[i];
+    const uint32_t d = (k >> shift) & mask;
+    const int64_t pos = (int64_t)gbase[d] + (i - dstart[d]);
+    keys_out[pos] = k;
+    vals_out[pos] = sval[i];
+  }
+}
+
+// ---- rowptr from the sorted keys, col / w from the sorted values --------------------------------------------
+template <class VAL>
+__global__ void __launch_bounds__(256) k_finish_csr(const uint32_t* __restrict__ keys, const VAL* __restrict__ vals,
+                                                    int64_t num_edges, int64_t num_rows, int32_t* __restrict__ rowptr,
+                                                    int32_t* __restrict__ col, float* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    // key sequence extended with -1 in front and num_rows behind; invalid edges carry key == num_rows
+    const int64_t prev = i == 0 ? -1 : (int64_t)keys[i - 1];
+    const int64_t cur = i == num_edges ? num_rows : (int64_t)keys[i];
+    for (int64_t r = prev + 1; r <= cur && r <= num_rows; ++r) rowptr[r] = (int32_t)i;
+    if (i < num_edges && cur < num_rows) {
+      const VAL v = vals[i];
+      col[i] = (int32_t)(uint32_t)v;
+      if constexpr (sizeof(VAL) == 8) w[i] = __uint_as_float((uint32_t)(v >> 32));
+    }
+  }
+}
+
+// ---- degree bins ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bin_count(const int32_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ bin_count,
+                                                   int32_t* __restrict__ stats) {
+  __shared__ int lbin[FSW_NUM_BINS];
+  __shared__ int lmax;
+  if (threadIdx.x < FSW_NUM_BINS) lbin[threadIdx.x] = 0;
+  if (threadIdx.x == 0) lmax = 0;
+  __syncthreads();
+  int mx = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    const int deg = rowptr[r + 1] - rowptr[r];
+    atomicAdd(&lbin[degree_bin(deg)], 1);
+    mx = max(mx, deg);
+  }
   atomicMax(&lmax, mx);
   __syncthreads();
   if (threadIdx.x < FSW_NUM_BINS && lbin[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], lbin[threadIdx.x]);
@@ -170,22 +343,6 @@ __global__ void k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __
   }
 }
 
-// ---- pass 3: scatter senders (and weights) into their rows ----------------------------------------
-__global__ void __launch_bounds__(256) k_scatter(const int64_t* __restrict__ recipients, const int64_t* __restrict__ senders,
-                                                 const float* __restrict__ edge_w, int64_t num_edges, int64_t num_rows,
-                                                 int64_t num_cols, int32_t* __restrict__ cursor, int32_t* __restrict__ col,
-                                                 float* __restrict__ w) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges; e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = recipients[e];
-    int64_t c = senders[e];
-    if (r < 0 || r >= num_rows || c < 0 || c >= num_cols) continue;
-    int pos = atomicAdd(&cursor[r], 1);
-    col[pos] = (int32_t)c;
-    if (edge_w) w[pos] = edge_w[e];
-  }
-}
-
-// ---- pass 4: rows ordered by degree bin ------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ rowptr, int64_t n,
                                                   int32_t* __restrict__ bin_cursor, int32_t* __restrict__ perm) {
   __shared__ int lcount[FSW_NUM_BINS];
@@ -204,14 +361,88 @@ __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ ro
   if (r < n) perm[lbase[bin] + rank] = (int32_t)r;
 }
 
+// ---- workspace ---------------------------------------------------------------------------------------------------
+struct GraphWs {
+  uint32_t* keys[2];
+  void* vals[2];
+  int32_t* counts;      // [ndigits][ntiles]
+  int32_t* block_sums;  // scan scratch
+  int32_t* bin_count;
+  int32_t* bin_cursor;
+  size_t total;
+};
+
+static GraphWs carve(void* ws, int64_t num_edges) {
+  const size_t E = (size_t)std::max<int64_t>(num_edges, 1);
+  const size_t ntiles = (size_t)ceil_div((int64_t)E, kRsTile);
+  char* p = reinterpret_cast<char*>(ws);
+  GraphWs g;
+  auto take = [&](size_t bytes) {
+    char* q = p;
+    p += align_up(bytes, 256);
+    return q;
+  };
+  g.keys[0] = reinterpret_cast<uint32_t*>(take(4 * E));
+  g.keys[1] = reinterpret_cast<uint32_t*>(take(4 * E));
+  g.vals[0] = take(8 * E);
+  g.vals[1] = take(8 * E);
+  g.counts = reinterpret_cast<int32_t*>(take(4 * (size_t)kRsMaxDigits * ntiles));
+  g.block_sums = reinterpret_cast<int32_t*>(take(4 * (size_t)(ceil_div((int64_t)(kRsMaxDigits * ntiles), kScanTile) + 1)));
+  g.bin_count = reinterpret_cast<int32_t*>(take(512));
+  g.bin_cursor = reinterpret_cast<int32_t*>(take(512));
+  g.total = (size_t)(p - reinterpret_cast<char*>(ws));
+  return g;
+}
+
+template <class VAL>
+static int sort_and_finish(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                           int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* stats,
+                           GraphWs& g, hipStream_t stream) {
+  int keybits = 1;
+  while ((1ll << keybits) <= num_rows) ++keybits;  // values 0 .. num_rows (sentinel) must fit
+  const int npass = (keybits + 7) / 8;
+  const int bits = (keybits + npass - 1) / npass;
+  const int64_t ntiles = ceil_div(num_edges, kRsTile);
+  int cur = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int shift = pass * bits;
+    const int ndigits = 1 << bits;
+    const uint32_t* kin = g.keys[cur];
+    const VAL* vin = reinterpret_cast<const VAL*>(g.vals[cur]);
+    uint32_t* kout = g.keys[cur ^ 1];
+    VAL* vout = reinterpret_cast<VAL*>(g.vals[cur ^ 1]);
+    if (pass == 0)
+      k_rs_upsweep<true><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(recipients, senders, edge_w, nullptr, num_edges, num_rows,
+                                                                      num_cols, shift, ndigits, g.counts, ntiles, stats);
+    else
+      k_rs_upsweep<false><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, num_edges, num_rows,
+                                                                       num_cols, shift, ndigits, g.counts, ntiles, stats);
+    FSW_LAUNCH_CHECK();
+    int rc = exclusive_scan_i32(g.counts, (int64_t)ndigits * ntiles, g.block_sums, stream);
+    if (rc) return rc;
+    if (pass == 0)
+      k_rs_downsweep<true, VAL><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(recipients, senders, edge_w, nullptr, nullptr, num_edges,
+                                                                             num_rows, num_cols, shift, bits, g.counts, ntiles, kout, vout);
+    else
+      k_rs_downsweep<false, VAL><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, vin, num_edges, num_rows,
+                                                                              num_cols, shift, bits, g.counts, ntiles, kout, vout);
+    FSW_LAUNCH_CHECK();
+    cur ^= 1;
+  }
+  const int blocks = (int)std::min<int64_t>(ceil_div(num_edges + 1, 256), 256 * 32);
+  k_finish_csr<VAL><<<blocks, 256, 0, stream>>>(g.keys[cur], reinterpret_cast<const VAL*>(g.vals[cur]), num_edges, num_rows, rowptr, col, w);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace fsw
 
 using namespace fsw;
 
 extern "C" size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges) {
-  (void)num_edges;
-  return align_up(sizeof(int32_t) * (size_t)(num_rows + 1), 256) +
-         align_up(sizeof(int32_t) * (size_t)(ceil_div(num_rows, kScanTile) + 1), 256) + 512;
+  (void)num_rows;
+  GraphWs g = carve(nullptr, num_edges);
+  return g.total;
 }
 
 extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
@@ -219,8 +450,8 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
                                int32_t* bin_start, int32_t* stats, void* workspace, size_t workspace_bytes,
                                fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) && num_cols >= 1 && num_cols < (1ll << 31) && num_edges >= 0 &&
-                  num_edges < (1ll << 31),
+  FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) - 1 && num_cols >= 1 && num_cols < (1ll << 31) && num_edges >= 0 &&
+                  num_edges < (1ll << 31) - kRsTile,
               "fsw_graph_build: sizes must satisfy 1 <= rows, cols < 2^31 and 0 <= edges < 2^31 (got %lld, %lld, %lld)",
               (long long)num_rows, (long long)num_cols, (long long)num_edges);
   FSW_REQUIRE(workspace && workspace_bytes >= fsw_graph_workspace_bytes(num_rows, num_edges),
@@ -228,30 +459,22 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
   FSW_REQUIRE(rowptr && perm && bin_start && stats && (num_edges == 0 || (col && recipients && senders)),
               "fsw_graph_build: null pointer");
   FSW_REQUIRE(!edge_w || w, "fsw_graph_build: edge_w given but w is null");
-  GraphWs g = carve(workspace, num_rows);
-  const int64_t nb = ceil_div(num_rows, kScanTile);
+  GraphWs g = carve(workspace, num_edges);
 
-  FSW_CHECK_HIP(hipMemsetAsync(g.cursor, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
   FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, 512, stream));
   FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
-
-  const int edge_blocks = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(num_edges, 256 * 4), 1), 256 * 16);
-  if (num_edges > 0) {
-    k_degree_hist<<<edge_blocks, 256, 0, stream>>>(recipients, senders, edge_w, num_edges, num_rows, num_cols, g.cursor, stats);
-    FSW_LAUNCH_CHECK();
+  if (num_edges == 0) {
+    FSW_CHECK_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
+  } else {
+    int rc = edge_w ? sort_and_finish<unsigned long long>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream)
+                    : sort_and_finish<uint32_t>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream);
+    if (rc) return rc;
   }
-  k_scan_partial<<<(int)nb, kScanThreads, 0, stream>>>(g.cursor, num_rows, g.block_sums);
-  FSW_LAUNCH_CHECK();
-  k_scan_block_sums<<<1, kScanThreads, 0, stream>>>(g.block_sums, nb);
-  FSW_LAUNCH_CHECK();
-  k_scan_final<<<(int)nb, kScanThreads, 0, stream>>>(g.cursor, num_rows, g.block_sums, rowptr, g.bin_count, stats);
+  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 256 * 16);
+  k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, g.bin_count, stats);
   FSW_LAUNCH_CHECK();
   k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
   FSW_LAUNCH_CHECK();
-  if (num_edges > 0) {
-    k_scatter<<<edge_blocks, 256, 0, stream>>>(recipients, senders, edge_w, num_edges, num_rows, num_cols, g.cursor, col, w);
-    FSW_LAUNCH_CHECK();
-  }
   k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm);
   FSW_LAUNCH_CHECK();
   return 0;
