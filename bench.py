@@ -87,7 +87,7 @@ def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
     out = torch.empty((n, conv.embed_dim + conv.in_channels), dtype=torch.float32, device=dev)
 
     def project():
-        _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), S, D_FEAT, Xp.data_ptr(), ldp, None, stream), "project")
+        _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), S, D_FEAT, Xp.data_ptr(), ldp, out.data_ptr() + 4 * conv.embed_dim, out.stride(0), None, stream), "project")
 
     def table_fn():
         _lib.check(L.fsw_unit_coeff_table(fr.data_ptr(), S, 32, table.data_ptr(), ldp, stream), "table")

@@ -18,7 +18,8 @@ constexpr int PBM = 128, PBN = 128, PBK = 32, PLD = PBK + 1;
 
 template <bool VEC>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0,
-                                           int kmax, float (*dst)[PLD], int& nonfinite) {
+                                           int kmax, float (*dst)[PLD], int& nonfinite, float* __restrict__ copy_dst = nullptr,
+                                           int64_t ld_copy = 0) {
   // 128 rows x 32 k; thread t covers k-quad (t & 7) of rows (t >> 3) + 32 i
   const int kq = (threadIdx.x & 7) * 4;
   const int r0 = threadIdx.x >> 3;
@@ -42,6 +43,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_
     for (int j = 0; j < 4; ++j) {
       nonfinite |= !(fabsf(v[j]) <= 3.402823466e38f);
       dst[r][kq + j] = v[j];
+      if (copy_dst && gr < nrows && k0 + kq + j < kmax) copy_dst[gr * ld_copy + k0 + kq + j] = v[j];
     }
   }
 }
@@ -49,7 +51,8 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
                                                  const float* __restrict__ V, int S, int64_t ldv, float* __restrict__ Xp,
-                                                 int64_t ldp, int32_t* __restrict__ stats, int nct) {
+                                                 int64_t ldp, int32_t* __restrict__ stats, int nct,
+                                                 float* __restrict__ x_copy, int64_t ld_copy) {
   __shared__ float As[PBM][PLD];
   __shared__ float Bs[PBN][PLD];
   const int ct = blockIdx.x % nct;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 
   int nonfinite = 0, dummy = 0;
   for (int k0 = 0; k0 < d; k0 += PBK) {
-    stage_tile<VEC>(X, ldx, row0, n, k0, d, As, nonfinite);
+    stage_tile<VEC>(X, ldx, row0, n, k0, d, As, nonfinite, ct == 0 ? x_copy : nullptr, ld_copy);
     stage_tile<VEC>(V, ldv, col0, S, k0, d, Bs, dummy);
     __syncthreads();
 #pragma unroll
@@ -108,9 +111,10 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 using namespace fsw;
 
 extern "C" int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
-                               float* Xp, int64_t ldp, int32_t* stats, fsw_stream_t stream_) {
+                               float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(X && V && Xp, "fsw_project_f32: null pointer");
+  FSW_REQUIRE(!x_copy || ld_copy >= d, "fsw_project_f32: ld_copy must be >= d");
   FSW_REQUIRE(n >= 1 && d >= 1 && S >= 1 && ldx >= d && ldv >= d && ldp >= S, "fsw_project_f32: bad sizes n=%lld d=%d S=%d",
               (long long)n, d, S);
   const int nct = (int)ceil_div(S, PBN);
@@ -118,9 +122,9 @@ extern "C" int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, co
   FSW_REQUIRE(nblocks < (1ll << 31), "fsw_project_f32: grid too large");
   const bool vec = (ldx % 4 == 0) && (ldv % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)V % 16 == 0);
   if (vec)
-    k_project<true><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct);
+    k_project<true><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy);
   else
-    k_project<false><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct);
+    k_project<false><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy);
   FSW_LAUNCH_CHECK();
   return 0;
 }

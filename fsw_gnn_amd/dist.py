@@ -44,17 +44,19 @@ def all_gather_slice_blocks(local, parts, has_mass, out, group=None):
     return out
 
 
-def sharded_embed_into(emb_mod, X, graph, out, out_scale=1.0, group=None):
+def sharded_embed_into(emb_mod, X, graph, out, out_scale=1.0, group=None, x_copy=None):
     """Slice-sharded version of FSW_embedding.embed_into: every rank ends with the full embedding in `out`."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
-        return emb_mod.embed_into(X, graph, out, out_scale=out_scale)
+        return emb_mod.embed_into(X, graph, out, out_scale=out_scale, x_copy=x_copy)
     has_mass = 1 if emb_mod.encode_total_mass else 0
     parts = slice_partition(emb_mod.nSlices, world)
     wmax = max(b - a for a, b in parts)
     ka, kb = parts[rank]
     local = torch.zeros((graph.num_rows, has_mass + wmax), dtype=X.dtype, device=X.device)
     if kb > ka:
-        emb_mod.embed_into(X, graph, local, out_scale=out_scale, slice_range=(ka, kb))
+        emb_mod.embed_into(X, graph, local, out_scale=out_scale, slice_range=(ka, kb), x_copy=x_copy)
+    elif x_copy is not None:
+        x_copy.copy_(X)
     return all_gather_slice_blocks(local, parts, has_mass, out, group)

@@ -192,13 +192,12 @@ class FSW_conv(_Base):
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
         scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
+        xc = buf[:, E:] if self.concat_self else None   # right half of cat((emb, x)), stored by the projection kernel
         if getattr(self, '_slice_parallel', False):
             from .dist import sharded_embed_into
-            sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=self._slice_parallel_group)
+            sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=self._slice_parallel_group, x_copy=xc)
         else:
-            emb_mod.embed_into(x, graph, buf, out_scale=scale)
-        if self.concat_self:
-            buf[:, E:] = x
+            emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)
         if self.mlp is not None:
             out = self.mlp(buf)
         elif self.concat_self:

@@ -300,17 +300,21 @@ class FSW_embedding(nn.Module):
         return out.reshape(out_shape + (self.d_out,))
 
     # ------------------------------------------------------------------------------------------------
-    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None):
+    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None):
         """Writes out_scale * E(X, graph) into the left columns of `out` (row stride out.stride(0)).
 
         X [num_cols, d_in] float32 contiguous; out [num_rows, >= width] float32 with unit inner stride, where
         width = d_out, or total_mass_dim + (kb - ka) when slice_range = (ka, kb) restricts the call to a block of
         slices (multi-GPU slice sharding, dist.py: column 0 is still the total-mass column, then slices ka..kb-1).
+        x_copy (optional [num_cols, d_in] view with unit inner stride): the projection kernel also stores X there
+        (FSW_conv's concat buffer, reference fsw_conv.py:357-358).
         This is the hot path: projection (MFMA) -> coefficient table -> fused neighbourhood kernels.
         """
         L = _lib.lib()
         dev = X.device
         has_mass = 1 if self.encode_total_mass else 0
+        if x_copy is not None:
+            assert x_copy.shape == X.shape and x_copy.stride(1) == 1 and x_copy.dtype == X.dtype
         ka, kb = (0, self.nSlices) if slice_range is None else slice_range
         assert 0 <= ka < kb <= self.nSlices or self.d_out == 0, 'bad slice_range'
         S = kb - ka
@@ -346,7 +350,9 @@ class FSW_embedding(nn.Module):
             Sc = k1 - k0
             Vc = V[k0:k1]
             rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
-                                   _lib.ptr(Xp), ldp, _lib.ptr(graph.stats_dev) if k0 == 0 else None, stream)
+                                   _lib.ptr(Xp), ldp, _lib.ptr(x_copy) if k0 == 0 else None,
+                                   x_copy.stride(0) if x_copy is not None else 0,
+                                   _lib.ptr(graph.stats_dev) if k0 == 0 else None, stream)
             _lib.check(rc, "fsw_project_f32")
             if st is None:
                 # one device->host read per forward: validation flags (fused into the kernels) + degree classes

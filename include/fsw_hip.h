@@ -84,9 +84,12 @@ int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const flo
 
 /* ---- projection: Xp[n, ldp] = X[n, ldx] . V[S, ldv]^T, fp32 MFMA (v_mfma_f32_32x32x2_f32) -------
  * Replaces torch.tensordot(X, projVecs) (reference fsw_embedding.py:909-913).  Sets
- * FSW_FLAG_X_NONFINITE in stats[FSW_STAT_FLAGS] if X holds a NaN/Inf (stats may be NULL).          */
+ * FSW_FLAG_X_NONFINITE in stats[FSW_STAT_FLAGS] if X holds a NaN/Inf (stats may be NULL).
+ * x_copy (nullable): the kernel also stores the X rows it stages to x_copy[i*ld_copy + c] -- this is
+ * the right half of FSW_conv's torch.cat((emb, vertex_features)) (reference fsw_conv.py:357-358),
+ * written while X is on chip anyway instead of by a separate copy kernel.                          */
 int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
-                    float* Xp, int64_t ldp, int32_t* stats, fsw_stream_t stream);
+                    float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream);
 
 /* ---- unit-weight readout coefficients ------------------------------------------------------------
  * table[(D*(D-1)/2 + t) * ldt + k] = (1+xi_k) * [sin(2 pi xi_k (t+1)/D) - sin(2 pi xi_k t/D)] / (pi xi_k)

@@ -60,14 +60,16 @@ def test_projection_mfma_vs_float64(dev):
         ldp = (S + 63) // 64 * 64
         Xp = torch.full((n, ldp), float("nan"), device=dev)
         stats = torch.zeros(8, dtype=torch.int32, device=dev)
-        rc = L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, stats.data_ptr(),
-                               torch.cuda.current_stream().cuda_stream)
+        xc = torch.full((n, d + 3), -1.0, device=dev)
+        rc = L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, xc.data_ptr() + 4, d + 3,
+                               stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0
+        assert torch.equal(xc[:, 1:d + 1], Xd) and (xc[:, 0] == -1).all() and (xc[:, d + 1:] == -1).all()
         ref = X.astype(np.float64) @ V.astype(np.float64).T
         assert relerr(Xp[:, :S].cpu().numpy(), ref) < 5e-7      # fp32 fma chain over d terms
         assert int(stats[0]) == 0
     Xd[5, 1] = float("inf")
-    L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, stats.data_ptr(),
+    L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, None, 0, stats.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
     assert int(stats[0]) & _lib.FLAG_X_NONFINITE
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert L.fsw_abi_version() == 1 and L.fsw_arch() == b"gfx950"
     # size helpers are pure host functions
     assert L.fsw_unit_table_rows(32) == 528
-    assert L.fsw_graph_workspace_bytes(1000, 10) > 4004
+    assert L.fsw_graph_workspace_bytes(1000, 10_000) >= 24 * 10_000      # two (key, value) ping-pong buffers
     assert L.fsw_embed_scratch_bytes(100) == 0 and L.fsw_embed_scratch_bytes(5000) > 0
     assert L.fsw_segcumsum_workspace_bytes(10_000) >= 5 * 12
 
