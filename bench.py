@@ -13,7 +13,7 @@ the timed region.  With N > 1 the slice axis is sharded over the ranks (256 / N 
 strong scaling) and reassembled by one RCCL all-gather.
 
 The JSON line also carries
-  roofline     the dominant kernel (k_embed_reg_unit) timed alone with HIP events on the launch stream:
+  roofline     the dominant kernel (k_conv_fused_unit; k_embed_reg_unit with --no-fuse) timed alone, HIP events on the launch stream:
                achieved = its algorithmic bytes per launch / mean duration, against the 8 TB/s HBM peak;
   cpu_baseline the C oracle (a port of the reference algorithm, oracle/fsw_oracle.c) on this box's host cores,
                rank 0 at N = 1 only, on a bounded sample of the same workload.
@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--edges", type=int, default=N_EDGES)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-slices", type=int, default=16)
+    ap.add_argument("--cpu-slices", type=int, default=64)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
     return ap.parse_args()
 
 
@@ -72,70 +74,74 @@ def timed_ms(fn, reps, dev):
 
 
 def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
-    """Times k_embed_reg_unit alone (the launch that gathers E*S projected values) and the other stages."""
+    """Times the dominant kernel of the step alone (HIP events on the launch stream) plus the other stages.
+
+    Dominant kernel = k_conv_fused_unit (neighbourhood gather/sort/readout fused with the first Linear layer) when
+    FSW_conv takes its fused path, else k_embed_reg_unit.  Both gather Xp[src, k] for every (edge, slice).
+    """
     from fsw_gnn_amd import _lib
     L = _lib.lib()
     emb = conv.fsw_embed
     S = emb.nSlices
     stream = torch.cuda.current_stream(dev).cuda_stream
     graph = conv.build_graph(ei, n)
-    st = graph.stats()
-    ldp = (S + 63) // 64 * 64
-    Xp = torch.empty((n, ldp), dtype=torch.float32, device=dev)
-    V, fr = emb.projVecs.detach(), emb.freqs.detach()
-    table = torch.empty((int(L.fsw_unit_table_rows(32)), ldp), dtype=torch.float32, device=dev)
-    out = torch.empty((n, conv.embed_dim + conv.in_channels), dtype=torch.float32, device=dev)
-
-    def project():
-        _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), S, D_FEAT, Xp.data_ptr(), ldp, out.data_ptr() + 4 * conv.embed_dim, out.stride(0), None, stream), "project")
-
-    def table_fn():
-        _lib.check(L.fsw_unit_coeff_table(fr.data_ptr(), S, 32, table.data_ptr(), ldp, stream), "table")
-
-    a = _lib.EmbedArgs()
-    a.rowptr, a.col, a.w = graph.rowptr.data_ptr(), graph.col.data_ptr(), None
-    a.perm, a.bin_start, a.num_rows = graph.perm.data_ptr(), graph.bin_start.data_ptr(), n
-    a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, fr.data_ptr(), S, 1.0
-    a.unit_table, a.ldt = table.data_ptr(), ldp
-    a.out, a.ldo, a.bias, a.out_scale = out.data_ptr(), out.stride(0), None, 1.0
-    a.has_mass, a.mass_fn, a.mass_scale = 1, 0, 1.0
-    a.num_reg_rows, a.num_lds_rows, a.num_global_rows, a.num_zero_rows = st[_lib.STAT_NUM_REG], 0, 0, 0
-    a.max_degree, a.scratch, a.scratch_bytes = st[_lib.STAT_MAX_DEGREE], None, 0
+    fused = conv._fusable()
+    y = torch.empty((n, conv.mlp[0].out_features), dtype=torch.float32, device=dev)
+    if fused:
+        wq, w2 = conv._fused_weight()
+        lin2 = (w2, conv.mlp[0].bias.detach(), y)
+    prepared = emb.prepare(x, graph, linear2=lin2 if fused else None)
+    st = prepared["stats"]
     assert st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0, "config 3 is expected to sit on the register path"
+    Xp, ldp, table = prepared["Xp"], prepared["ldp"], prepared["table"]
+    V, fr = emb.projVecs.detach(), emb.freqs.detach()
+    out = torch.empty((n, conv.embed_dim + conv.in_channels), dtype=torch.float32, device=dev)
+    def project():
+        if fused:   # projection + the x . W2^T + b half of the first Linear layer
+            emb.prepare(x, graph, linear2=lin2)
+        else:
+            _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), S, D_FEAT, Xp.data_ptr(), ldp,
+                                         out.data_ptr() + 4 * conv.embed_dim, out.stride(0), None, stream), "project")
+
+    a = emb.make_args(graph, st, Xp, ldp, fr, S, table, out.data_ptr(), out.stride(0), None, 1.0, 1)
+    a.num_zero_rows = 0                                # the timed call is exactly one launch: k_embed_reg_unit
 
     def embed():
-        _lib.check(L.fsw_embed_f32(ctypes.byref(a), stream), "embed")   # exactly one launch: k_embed_reg_unit
+        _lib.check(L.fsw_embed_f32(ctypes.byref(a), stream), "embed")
 
-    project()
-    table_fn()
     ms = {
         "csr_build": timed_ms(lambda: conv.build_graph(ei, n), max(3, reps // 4), dev),
         "project": timed_ms(project, max(3, reps // 4), dev),
         "embed_reg_unit": timed_ms(embed, reps, dev),
     }
-    lin = conv.mlp
-    ms["concat_mlp"] = timed_ms(lambda: lin(out), max(3, reps // 4), dev)
-    # algorithmic bytes of ONE k_embed_reg_unit launch (DESIGN.md "roofline"): the gather of Xp[src, k] for every
-    # (edge, slice), the int32 CSR (col, rowptr, perm) read once, the embedding written once
     rows_reg = st[_lib.STAT_NUM_REG]
     edges = int(graph.rowptr[-1])
-    alg_bytes = 4.0 * edges * S + 4.0 * edges + 8.0 * rows_reg + 4.0 * rows_reg * (S + 1)
-    secs = ms["embed_reg_unit"] * 1e-3
+    gather_bytes = 4.0 * edges * S + 4.0 * edges + 8.0 * n        # Xp gather + col + rowptr/perm
+    if fused:
+        ms["conv_fused_unit"] = timed_ms(lambda: conv._fused_linear(graph, prepared, 1.0, wq, y), reps, dev)
+        kernel, kms = "k_conv_fused_unit", ms["conv_fused_unit"]
+        # + Y (= x . W2^T + b from the projection kernel) read once and written once (packed W1^T, 0.13 MB, stays in L2)
+        alg_bytes = gather_bytes + 8.0 * n * conv.mlp[0].out_features
+    else:
+        ms["mlp"] = timed_ms(lambda: conv.mlp(out), max(3, reps // 4), dev)
+        kernel, kms = "k_embed_reg_unit", ms["embed_reg_unit"]
+        alg_bytes = gather_bytes + 4.0 * rows_reg * (S + 1)       # + embedding written once
+    secs = kms * 1e-3
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     if os.path.isfile(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_embed_reg_unit_hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roof = {"bound": "hbm", "kernel": "k_embed_reg_unit", "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": ms["embed_reg_unit"],
+            "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kms,
             "bytes_per_edge_slice": alg_bytes / (float(e_coalesced) * S)}
     return roof, ms
 
 
-def cpu_baseline(x, ei, conv, n, nslices):
+def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     """C oracle (port of the reference algorithm) on the host cores: slices [0, nslices) of the same workload."""
     from oracle import c_oracle as C
     from oracle import fsw_oracle as O
@@ -146,7 +152,7 @@ def cpu_baseline(x, ei, conv, n, nslices):
     xh = x.cpu().numpy()
     V = conv.fsw_embed.projVecs.detach().cpu().numpy()
     fr = conv.fsw_embed.freqs.detach().cpu().numpy()
-    threads = C.max_threads()
+    threads = min(C.max_threads(), max_threads)        # the GPU box's CPU share for one GPU is 16 cores
     t0 = time.time()
     C.embed(xh, rowptr, col, None, V, fr, s0=0, s1=nslices, nthreads=threads)
     secs = time.time() - t0
@@ -174,6 +180,8 @@ def main():
     x, ei = make_inputs(n, E, dev)
     torch.manual_seed(4321)
     conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=EMBED_DIM, device=dev)
+    if args.no_fuse:
+        conv.fuse_linear = False
     if world > 1:
         conv.enable_slice_parallel(None)
     S = conv.fsw_embed.nSlices
@@ -224,7 +232,7 @@ def main():
         result["roofline"] = roof
         result["stage_ms"] = ms
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices)
+            result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -46,6 +46,11 @@ _SIGNATURES = {
     "fsw_unit_coeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_scratch_bytes": (c_sz, [c_i64]),
     "fsw_embed_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp]),
+    "fsw_conv_fused_lds_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "fsw_project_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64,
+                                              c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     "fsw_segcumsum_workspace_bytes": (c_sz, [c_i64]),
     "fsw_segcumsum": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_sz, c_vp]),
     # legacy ABI, exact reference signatures (reference fsw_embedding.py:2952-2977)

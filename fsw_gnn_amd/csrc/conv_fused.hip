@@ -1,0 +1,246 @@
+// FSW_conv fast path: neighbourhood embedding fused with the first Linear layer of the MLP.  gfx950.
+//
+//   Y[i, :] = act( [ mw * E(N(i)) , x_i ] . W^T + b )            (reference fsw_conv.py:355-362)
+//           = act( mw * E(N(i)) . W1^T  +  ( x_i . W2^T + b ) )   with W = [W1 | W2]
+//
+// for unit edge weights, tau <= 1 and in-degrees 0 .. FSW_REG_MAX_DEG.  The reference (and the unfused path of
+// this library) writes the embedding E to HBM (n x embed_dim floats), copies x next to it (torch.cat), reads
+// both back in a GEMM and makes one more pass for the activation.  Here
+//   * the x . W2^T + b half is folded into the projection GEMM (project.hip: extra output block), which already
+//     has every X tile in LDS, and lands in Y;
+//   * a workgroup keeps the 32 embedding rows it has just produced in LDS and multiplies the 32 x embed_dim tile
+//     by W1^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) while other workgroups of the CU
+//     are in their memory-bound gather phase -- the MFMA pipe is otherwise idle in this kernel; the epilogue adds
+//     the row of Y, applies the activation and stores it back.
+// Per 32 rows:
+//   phase 1  (= embed_reg.hip: k_embed_reg_unit) lane = slice, wave = 64-slice chunk: D coalesced 256-B gathers
+//            of Xp[col, k0..k0+63], exact-size min/max sorting network, D FMAs with the float64-evaluated
+//            coefficient table  ->  H[row][mass | slices] in LDS (odd row stride: conflict-free MFMA operand reads)
+//   phase 2  wave w owns output columns 32w..32w+31: A from LDS; B = W1^T packed on the host so that ONE 16-byte
+//            load per lane feeds four MFMAs (group of 8 k: [k, k+2, k+4, k+6 | k+1, k+3, k+5, k+7] per column),
+//            eight groups in flight per wave (the loads queue behind the CU's HBM gathers)
+//   phase 3  + Y row (x . W2^T + b), activation, rows scattered back to Y by node id
+// HBM traffic per forward drops by ~3.6 GB at BASELINE config 3 (no E write, no E/x re-read, no concat, no
+// activation pass).
+#include "fsw_common.h"
+#include "sortnet.h"
+
+namespace fsw {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kFusedRows = 32;
+
+struct FusedArgs {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const int32_t* perm;
+  const int32_t* bin_start;
+  const float* Xp;
+  int64_t ldp;
+  int S;
+  const float* table;
+  int64_t ldt;
+  const float* bias;  // embedding bias [has_mass + S] or null
+  float out_scale;    // message_weight_vs_self
+  int has_mass, mass_fn;
+  float mass_scale;
+  const float* Wq;  // packed W1^T: [Kp/8][ldw][8], zero padded (Kp = K rounded up to 8, ldw = Hout rounded up to 32)
+  int64_t ldw;
+  const float* lin_bias;  // [Hout] or null; used only when y_accumulate == 0
+  int y_accumulate;       // 1: Y already holds x . W2^T + b (written by the projection kernel)
+  int Hout;
+  int act;  // 0 none, 1 relu, 2 leaky relu
+  float slope;
+  float* Y;
+  int64_t ldy;
+  int ldh;  // LDS row stride of H (odd)
+  int Kp;
+};
+
+__device__ __forceinline__ float mass_encode_f(float m, int fn) {
+  if (fn == 1) return 2.f * (m / (sqrtf(m + 1.f) + 1.f));
+  if (fn == 2) return log1pf(m);
+  return m;
+}
+
+// phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS
+template <int D>
+__device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int nrows, float* __restrict__ H, int chunk) {
+  const int lane = lane_id();
+  const int k = chunk * kWave + lane;
+  const bool kvalid = k < a.S;
+  const int kc = kvalid ? k : a.S - 1;
+  const float b = a.bias ? a.out_scale * a.bias[a.has_mass + kc] : 0.f;
+  if constexpr (D == 0) {
+    for (int r = 0; r < nrows; ++r)
+      if (kvalid) H[r * a.ldh + a.has_mass + k] = b;
+  } else {
+    float coef[D];
+    const float* tab = a.table + (int64_t)(D * (D - 1) / 2) * a.ldt + kc;
+#pragma unroll
+    for (int t = 0; t < D; ++t) coef[t] = a.out_scale * tab[(int64_t)t * a.ldt];
+    for (int r = 0; r < nrows; ++r) {
+      const int node = a.perm[p + r];
+      const int start = a.rowptr[node];
+      KeyNet<D> net;
+#pragma unroll
+      for (int t = 0; t < D; ++t) {
+        const int c = a.col[start + t];
+        net.k[t] = a.Xp[(int64_t)c * a.ldp + kc];
+      }
+      sort_network<D>(net);
+      float acc = b;
+#pragma unroll
+      for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
+      if (kvalid) H[r * a.ldh + a.has_mass + k] = acc;
+    }
+  }
+}
+
+#define FSW_CASES_0_32(X)                                                                                                   \
+  X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
+  X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
+__global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* H = smem;                                                        // [kFusedRows][ldh]
+  int* nodeS = reinterpret_cast<int*>(smem + kFusedRows * a.ldh);         // [kFusedRows]
+
+  // workgroup -> (degree bin, perm range): one degree per workgroup, highest degrees first, bin 0 last
+  int D, p = 0, pe = 0;
+  {
+    int b = blockIdx.x;
+    for (D = FSW_REG_MAX_DEG; D >= 0; --D) {
+      const int lo = a.bin_start[D], hi = a.bin_start[D + 1];
+      const int nb = (hi - lo + kFusedRows - 1) / kFusedRows;
+      if (b < nb) {
+        p = lo + b * kFusedRows;
+        pe = min(p + kFusedRows, hi);
+        break;
+      }
+      b -= nb;
+    }
+    if (D < 0) return;
+  }
+  const int nrows = pe - p;
+  const int wv = wave_id();
+  const int lane = lane_id();
+  const int K = a.has_mass + a.S;  // embedding width = K of the fused product
+
+  // zero the K padding column(s) and the unused rows of H, record node ids, mass column
+  if (threadIdx.x < kFusedRows) {
+    const int r = threadIdx.x;
+    for (int c = (r < nrows ? K : 0); c < a.ldh; ++c) H[r * a.ldh + c] = 0.f;
+    nodeS[r] = r < nrows ? a.perm[p + r] : -1;
+    if (a.has_mass && r < nrows)
+      H[r * a.ldh] = a.out_scale * (mass_encode_f((float)D, a.mass_fn) * a.mass_scale + (a.bias ? a.bias[0] : 0.f));
+  }
+  // phase 1: embedding rows
+  const int nchunks = (a.S + kWave - 1) / kWave;
+  for (int chunk = wv; chunk < nchunks; chunk += 4) {
+    switch (D) {
+#define X(d)                                   \
+  case d:                                      \
+    fused_embed_rows<d>(a, p, nrows, H, chunk); \
+    break;
+      FSW_CASES_0_32(X)
+#undef X
+      default:
+        break;
+    }
+  }
+  __syncthreads();
+
+  // phase 2 + 3: Y tile = H . W1^T, one 32-column slab per wave and iteration
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nslabs = (a.Hout + 31) / 32;
+  const int ngroups = a.Kp >> 3;
+  for (int slab = wv; slab < nslabs; slab += 4) {
+    const int j0 = slab * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* hp = H + fr * a.ldh + fh;
+    const float4* wq = reinterpret_cast<const float4*>(a.Wq) + ((int64_t)(j0 + fr) * 2 + fh);
+    const int64_t gstride = a.ldw * 2;  // float4 units between consecutive k-groups
+    auto loadw = [&](int g) { return wq[(int64_t)min(g, ngroups - 1) * gstride]; };
+    auto mma4 = [&](int g, const float4& bq) {
+      const float* h = hp + 8 * g;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], bq.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], bq.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[4], bq.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[6], bq.w, acc, 0, 0, 0);
+    };
+    // W1^T comes from L2 while every other wave of the CU is streaming gathers from HBM: ~1 us per load under load.
+    // Keep kPrefetch groups (one 16-byte load each, four MFMAs = 256 cycles) in flight per wave.
+    constexpr int kPrefetch = 8;
+    float4 bq[kPrefetch];
+#pragma unroll
+    for (int u = 0; u < kPrefetch; ++u) bq[u] = loadw(u);
+    for (int g0 = 0; g0 < ngroups; g0 += kPrefetch) {
+#pragma unroll
+      for (int u = 0; u < kPrefetch; ++u) {
+        if (g0 + u < ngroups) mma4(g0 + u, bq[u]);
+        bq[u] = loadw(g0 + u + kPrefetch);
+      }
+    }
+
+    const int j = j0 + fr;
+    if (j < a.Hout) {
+      const float lb = (!a.y_accumulate && a.lin_bias) ? a.lin_bias[j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
+        const int node = nodeS[row];
+        if (node >= 0) {
+          float* yp = a.Y + (int64_t)node * a.ldy + j;
+          float y = acc[r] + lb;
+          if (a.y_accumulate) y += *yp;
+          if (a.act == 1) y = fmaxf(y, 0.f);
+          else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
+          *yp = y;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fsw
+
+using namespace fsw;
+
+extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
+  const int Kp = (has_mass + S + 7) & ~7;
+  const int ldh = Kp | 1;
+  return (size_t)kFusedRows * ldh * sizeof(float) + kFusedRows * sizeof(int);
+}
+
+extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
+                                  int y_accumulate, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  FSW_REQUIRE(args && Wq && Y, "fsw_conv_fused_f32: null pointer");
+  const fsw_embed_args& e = *args;
+  FSW_REQUIRE(e.rowptr && e.col && e.perm && e.bin_start && e.Xp && e.unit_table, "fsw_conv_fused_f32: null pointer in args");
+  FSW_REQUIRE(e.w == nullptr && e.tau <= 1.f, "fsw_conv_fused_f32: unit weights with tau <= 1 only");
+  FSW_REQUIRE(e.num_lds_rows == 0 && e.num_global_rows == 0,
+              "fsw_conv_fused_f32: rows with in-degree > %d must take the unfused path", FSW_REG_MAX_DEG);
+  FSW_REQUIRE(e.S >= 1 && e.ldp >= e.S && e.ldt >= e.S && (e.has_mass == 0 || e.has_mass == 1), "fsw_conv_fused_f32: bad sizes");
+  FSW_REQUIRE(Hout >= 1 && ldy >= Hout && ldw >= ((Hout + 31) / 32) * 32 && ldw % 32 == 0, "fsw_conv_fused_f32: bad output sizes");
+  FSW_REQUIRE(((uintptr_t)Wq & 15) == 0, "fsw_conv_fused_f32: Wq must be 16-byte aligned");
+  FSW_REQUIRE(act >= 0 && act <= 2, "fsw_conv_fused_f32: act must be 0 (none), 1 (relu) or 2 (leaky relu)");
+  const size_t lds = fsw_conv_fused_lds_bytes(e.S, e.has_mass);
+  FSW_REQUIRE(lds <= 64 * 1024, "fsw_conv_fused_f32: embed_dim too wide for the fused tile (%zu B of LDS)", lds);
+  FusedArgs a;
+  a.rowptr = e.rowptr; a.col = e.col; a.perm = e.perm; a.bin_start = e.bin_start;
+  a.Xp = e.Xp; a.ldp = e.ldp; a.S = e.S; a.table = e.unit_table; a.ldt = e.ldt;
+  a.bias = e.bias; a.out_scale = e.out_scale; a.has_mass = e.has_mass; a.mass_fn = e.mass_fn; a.mass_scale = e.mass_scale;
+  a.Wq = Wq; a.ldw = ldw; a.lin_bias = lin_bias; a.y_accumulate = y_accumulate ? 1 : 0; a.Hout = Hout; a.act = act; a.slope = slope;
+  a.Y = Y; a.ldy = ldy;
+  a.Kp = (e.has_mass + e.S + 7) & ~7;
+  a.ldh = a.Kp | 1;
+  const int64_t nblocks = ceil_div(e.num_rows, kFusedRows) + FSW_REG_MAX_DEG + 1;
+  k_conv_fused_unit<<<(unsigned)nblocks, 256, lds, stream>>>(a);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}

@@ -8,6 +8,7 @@
 //
 // Tiling: 256 threads = 4 waves as 2x2; workgroup tile 128 rows x 128 slices, K step 32 through LDS;
 // each wave owns a 64x64 sub-tile = 2x2 MFMA blocks of 32x32 (64 accumulator registers).
+#include <algorithm>
 #include "fsw_common.h"
 
 namespace fsw {
@@ -16,20 +17,20 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int PBM = 128, PBN = 128, PBK = 32, PLD = PBK + 1;
 
-template <bool VEC>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows, int k0,
-                                           int kmax, float (*dst)[PLD], int& nonfinite, float* __restrict__ copy_dst = nullptr,
-                                           int64_t ld_copy = 0) {
-  // 128 rows x 32 k; thread t covers k-quad (t & 7) of rows (t >> 3) + 32 i
+// Stage 128 rows x 32 k of a row-major matrix into LDS; rowp(r) returns the global row pointer of tile row r
+// (or nullptr for rows past the end, which are zero filled).  thread t covers k-quad (t & 7) of rows (t >> 3) + 32 i.
+template <bool VEC, class RowPtr>
+__device__ __forceinline__ void stage_tile(RowPtr rowp, int k0, int kmax, float (*dst)[PLD], int& nonfinite,
+                                           float* __restrict__ copy_dst, int64_t ld_copy, int64_t row0) {
   const int kq = (threadIdx.x & 7) * 4;
   const int r0 = threadIdx.x >> 3;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + 32 * i;
-    const int64_t gr = row0 + r;
+    const float* src = rowp(r);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gr < nrows) {
-      const float* p = src + gr * ld + k0 + kq;
+    if (src) {
+      const float* p = src + k0 + kq;
       if (VEC && k0 + kq + 3 < kmax) {
         float4 q = *reinterpret_cast<const float4*>(p);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
@@ -43,16 +44,20 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_
     for (int j = 0; j < 4; ++j) {
       nonfinite |= !(fabsf(v[j]) <= 3.402823466e38f);
       dst[r][kq + j] = v[j];
-      if (copy_dst && gr < nrows && k0 + kq + j < kmax) copy_dst[gr * ld_copy + k0 + kq + j] = v[j];
+      if (copy_dst && src && k0 + kq + j < kmax) copy_dst[(row0 + r) * ld_copy + k0 + kq + j] = v[j];
     }
   }
 }
 
+// Columns 0 .. S-1 of the product go to Xp (rows of V); columns S .. S+H2-1 are an optional second block
+// Y2 = X . W2^T + b2 (rows of W2): the x half of FSW_conv's first Linear layer (conv_fused.hip).
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
                                                  const float* __restrict__ V, int S, int64_t ldv, float* __restrict__ Xp,
                                                  int64_t ldp, int32_t* __restrict__ stats, int nct,
-                                                 float* __restrict__ x_copy, int64_t ld_copy) {
+                                                 float* __restrict__ x_copy, int64_t ld_copy,
+                                                 const float* __restrict__ W2, int H2, int64_t ldw2,
+                                                 const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2) {
   __shared__ float As[PBM][PLD];
   __shared__ float Bs[PBN][PLD];
   const int ct = blockIdx.x % nct;
@@ -63,6 +68,7 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
   const int wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1;
   const int fr = lane & 31, fh = lane >> 5;
+  const int N = S + H2;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -72,10 +78,15 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  auto a_row = [&](int r) -> const float* { return row0 + r < n ? X + (row0 + r) * ldx : nullptr; };
+  auto b_row = [&](int r) -> const float* {
+    const int c = col0 + r;
+    return c < S ? V + (int64_t)c * ldv : (c < N ? W2 + (int64_t)(c - S) * ldw2 : nullptr);
+  };
   int nonfinite = 0, dummy = 0;
   for (int k0 = 0; k0 < d; k0 += PBK) {
-    stage_tile<VEC>(X, ldx, row0, n, k0, d, As, nonfinite, ct == 0 ? x_copy : nullptr, ld_copy);
-    stage_tile<VEC>(V, ldv, col0, S, k0, d, Bs, dummy);
+    stage_tile<VEC>(a_row, k0, d, As, nonfinite, ct == 0 ? x_copy : nullptr, ld_copy, row0);
+    stage_tile<VEC>(b_row, k0, d, Bs, dummy, nullptr, 0, 0);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < PBK; kk += 2) {
@@ -97,12 +108,129 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = col0 + wc * 64 + j * 32 + fr;
+      if (c >= N) continue;
+      const bool second = c >= S;
+      float* dst = second ? Y2 + (c - S) : Xp + c;
+      const int64_t ld = second ? ldy2 : ldp;
+      const float add = (second && b2) ? b2[c - S] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gr = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (gr < n && c < S) Xp[gr * ldp + c] = acc[i][j][r];
+        if (gr < n) dst[gr * ld] = acc[i][j][r] + add;
       }
     }
+  if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
+}
+
+// ---- B-stationary variant (d <= 128, 16-byte aligned rows) --------------------------------------------------------
+// The weight block [V; W2] is small (N x d <= 384 x 128 floats), so every wave keeps its 32-column slab of it in
+// registers for the whole kernel (one VGPR per k-pair: exactly the MFMA B operand) and the workgroup -- one wave per
+// slab, up to 12 -- streams 32-row tiles of X through a double-buffered LDS tile.  X is read from HBM exactly
+// once, nothing but X tiles moves through LDS, and the MFMA pipe sees back-to-back accumulate chains:
+//   per tile:  prefetch tile t+1 (global -> registers) | d/2 MFMAs from LDS tile t | store the 32x32 block,
+//              registers -> LDS tile t+1, one barrier.
+constexpr int BS_ROWS = 32, BS_LD = 129;
+
+template <int KQ>
+__global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                    const float* __restrict__ V, int S, int64_t ldv,
+                                                    float* __restrict__ Xp, int64_t ldp, int32_t* __restrict__ stats,
+                                                    float* __restrict__ x_copy, int64_t ld_copy,
+                                                    const float* __restrict__ W2, int H2, int64_t ldw2,
+                                                    const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
+                                                    int64_t ntiles, int nslab_waves) {
+  __shared__ float As[2][BS_ROWS][BS_LD];
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int N = S + H2;
+  const int slab = blockIdx.y * nslab_waves + wv;
+  const bool slab_active = wv < nslab_waves && slab * 32 < N;
+  const int c = slab_active ? slab * 32 + fr : N;       // this lane's output column (N = none)
+
+  // the slab of [V; W2] this wave multiplies by, as MFMA B operands: b[q] = W[c][2q + fh]
+  float b[KQ];
+  {
+    const float* wrow = c < S ? V + (int64_t)c * ldv : (c < N ? W2 + (int64_t)(c - S) * ldw2 : nullptr);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) b[q] = (wrow && 2 * q + fh < d) ? wrow[2 * q + fh] : 0.f;
+  }
+  const bool second = c >= S;
+  float* dst = c < N ? (second ? Y2 + (c - S) : Xp + c) : nullptr;
+  const int64_t ldd = second ? ldy2 : ldp;
+  const float add = (second && b2 && c < N) ? b2[c - S] : 0.f;
+
+  // zero the k-padding columns of both LDS tiles once (columns d .. 2 KQ)
+  for (int i = threadIdx.x; i < 2 * BS_ROWS * BS_LD; i += blockDim.x) (&As[0][0][0])[i] = 0.f;
+  __syncthreads();
+
+  const int d4 = d >> 2;                      // float4 per row
+  const int per_tile = BS_ROWS * d4;          // float4 per tile (<= 1024)
+  int nonfinite = 0;
+  auto load_tile = [&](int64_t tile, float4& q0, float4& q1) {
+    const int64_t row0 = tile * BS_ROWS;
+    q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    q1 = q0;
+    const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+    if (i0 < per_tile) {
+      const int r = i0 / d4, c4 = i0 - r * d4;
+      if (row0 + r < n) q0 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+    }
+    if (i1 < per_tile) {
+      const int r = i1 / d4, c4 = i1 - r * d4;
+      if (row0 + r < n) q1 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+    }
+  };
+  auto store_tile = [&](int buf, int64_t tile, const float4& q0, const float4& q1) {
+    const int64_t row0 = tile * BS_ROWS;
+    const int idx[2] = {(int)threadIdx.x, (int)(threadIdx.x + blockDim.x)};
+    const float4 q[2] = {q0, q1};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (idx[u] < per_tile) {
+        const int r = idx[u] / d4, c4 = idx[u] - r * d4;
+        const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          nonfinite |= !(fabsf(v[j]) <= 3.402823466e38f);
+          As[buf][r][4 * c4 + j] = v[j];
+          if (blockIdx.y == 0 && x_copy && row0 + r < n) x_copy[(row0 + r) * ld_copy + 4 * c4 + j] = v[j];
+        }
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  float4 q0, q1;
+  if (tile < ntiles) {
+    load_tile(tile, q0, q1);
+    store_tile(0, tile, q0, q1);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next, q0, q1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = &As[buf][fr][fh];
+    if (slab_active) {   // wave-uniform: helper waves (no slab) only move X tiles
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q], b[q], acc, 0, 0, 0);
+    }
+    if (dst) {
+      const int64_t row0 = tile * BS_ROWS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (gr < n) dst[gr * ldd] = acc[r] + add;
+      }
+    }
+    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
+    __syncthreads();
+    buf ^= 1;
+  }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
 }
 
@@ -110,21 +238,58 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 
 using namespace fsw;
 
-extern "C" int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
-                               float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  FSW_REQUIRE(X && V && Xp, "fsw_project_f32: null pointer");
-  FSW_REQUIRE(!x_copy || ld_copy >= d, "fsw_project_f32: ld_copy must be >= d");
-  FSW_REQUIRE(n >= 1 && d >= 1 && S >= 1 && ldx >= d && ldv >= d && ldp >= S, "fsw_project_f32: bad sizes n=%lld d=%d S=%d",
+static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv, float* Xp,
+                          int64_t ldp, float* x_copy, int64_t ld_copy, const float* W2, int H2, int64_t ldw2, const float* b2,
+                          float* Y2, int64_t ldy2, int32_t* stats, hipStream_t stream) {
+  FSW_REQUIRE(X && V && Xp, "fsw_project: null pointer");
+  FSW_REQUIRE(!x_copy || ld_copy >= d, "fsw_project: ld_copy must be >= d");
+  FSW_REQUIRE(n >= 1 && d >= 1 && S >= 1 && ldx >= d && ldv >= d && ldp >= S, "fsw_project: bad sizes n=%lld d=%d S=%d",
               (long long)n, d, S);
-  const int nct = (int)ceil_div(S, PBN);
+  FSW_REQUIRE(H2 == 0 || (W2 && Y2 && ldw2 >= d && ldy2 >= H2), "fsw_project: bad second output block");
+  const bool vec = (ldx % 4 == 0) && (ldv % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
+                   (H2 == 0 || ((ldw2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0)));
+  if (vec && d % 4 == 0 && d <= 128) {
+    // B-stationary kernel: one wave per 32-column slab (<= 16 waves per workgroup), persistent over 32-row tiles
+    // (<= 12 slab waves so that the 64 B-operand registers fit without spilling; >= 8 waves so that every X tile
+    //  is two 16-byte loads per thread -- waves without a slab only help moving X)
+    const int nslabs = (int)ceil_div(S + H2, 32);
+    const int ngroups = (int)ceil_div(nslabs, 12);
+    const int nwaves = (int)ceil_div(nslabs, ngroups);
+    const int64_t ntiles = ceil_div(n, BS_ROWS);
+    dim3 grid((unsigned)std::min<int64_t>(ntiles, 256), (unsigned)ngroups);
+    const int threads = std::max(nwaves, 8) * 64;
+#define FSW_LAUNCH_BS(KQ)                                                                                                \
+  k_project_bs<KQ><<<grid, threads, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, b2, \
+                                                 Y2, ldy2, ntiles, nwaves)
+    if (d <= 32) FSW_LAUNCH_BS(16);
+    else if (d <= 64) FSW_LAUNCH_BS(32);
+    else FSW_LAUNCH_BS(64);
+#undef FSW_LAUNCH_BS
+    FSW_LAUNCH_CHECK();
+    return 0;
+  }
+  const int nct = (int)ceil_div(S + H2, PBN);
   const int64_t nblocks = ceil_div(n, PBM) * nct;
-  FSW_REQUIRE(nblocks < (1ll << 31), "fsw_project_f32: grid too large");
-  const bool vec = (ldx % 4 == 0) && (ldv % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)V % 16 == 0);
+  FSW_REQUIRE(nblocks < (1ll << 31), "fsw_project: grid too large");
   if (vec)
-    k_project<true><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy);
+    k_project<true><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy, W2, H2,
+                                                           ldw2, b2, Y2, ldy2);
   else
-    k_project<false><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy);
+    k_project<false><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy, W2, H2,
+                                                            ldw2, b2, Y2, ldy2);
   FSW_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
+                               float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream) {
+  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, x_copy, ld_copy, nullptr, 0, 0, nullptr, nullptr, 0, stats,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
+                                      float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
+                                      int64_t ldy2, int32_t* stats, fsw_stream_t stream) {
+  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, nullptr, 0, W2, H2, ldw2, b2, Y2, ldy2, stats,
+                        reinterpret_cast<hipStream_t>(stream));
 }

@@ -11,11 +11,13 @@ When torch_geometric is importable the classes derive from MessagePassing and re
 graphgym under 'fsw_conv' / 'fsw_readout' like the reference (fsw_conv.py:54, 451); otherwise they are plain
 nn.Modules (the reference never calls propagate(): message/aggregate/update are empty stubs, :374-381).
 """
+import ctypes
 import inspect
 
 import numpy as np
 import torch
 
+from . import _lib
 from .fsw_embedding import FSW_embedding
 from .graph import build_csr
 
@@ -189,15 +191,37 @@ class FSW_conv(_Base):
         x = vertex_features.contiguous()
         graph = self.build_graph(edge_index, n)
         E = self.embed_dim
+        scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
+        sharded = getattr(self, '_slice_parallel', False)
+
+        prepared = None
+        if self._fusable() and not sharded:
+            # fast path: the projection GEMM also produces x . W2^T + b, then ONE kernel does the neighbourhood
+            # embedding and E . W1^T (+ activation); the embedding never reaches HBM (csrc/conv_fused.hip)
+            lin = self.mlp[0]
+            wq, w2 = self._fused_weight()
+            y = torch.empty((n, lin.out_features), dtype=x.dtype, device=x.device)
+            lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, y) if self.concat_self else None
+            prepared = emb_mod.prepare(x, graph, linear2=lin2)
+            st = prepared["stats"]
+            if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
+                next_module = self._fused_linear(graph, prepared, scale, wq, y)
+                for m in self.mlp[next_module:]:
+                    y = m(y)
+                return y
+
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
-        scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
-        xc = buf[:, E:] if self.concat_self else None   # right half of cat((emb, x)), stored by the projection kernel
-        if getattr(self, '_slice_parallel', False):
+        xc = buf[:, E:] if self.concat_self else None   # right half of cat((emb, x))
+        if sharded:
             from .dist import sharded_embed_into
             sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=self._slice_parallel_group, x_copy=xc)
+        elif prepared is not None:                       # fusable configuration, but the graph has long rows
+            emb_mod.embed_into(x, graph, buf, out_scale=scale, prepared=prepared)
+            if xc is not None:
+                xc.copy_(x)
         else:
-            emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)
+            emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)   # X stored by the projection kernel
         if self.mlp is not None:
             out = self.mlp(buf)
         elif self.concat_self:
@@ -207,6 +231,57 @@ class FSW_conv(_Base):
         if self.bn_final is not None:
             out = self.bn_final(out)
         return out
+
+    # ------------------------------------------------------------------------------------------------
+    fuse_linear = True   # class-level switch: set conv.fuse_linear = False to force the unfused kernels
+
+    def _fusable(self):
+        """Static conditions of the fused embedding + Linear kernel (csrc/conv_fused.hip)."""
+        emb = self.fsw_embed
+        if not (self.fuse_linear and self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear)):
+            return False
+        if self.self_loop_weight > 0 or self.edge_weighting != 'unit' or emb.total_mass_pad_thresh > 1.0:
+            return False
+        if emb.encode_total_mass and emb.total_mass_encoding_method != 'plain':
+            return False
+        return int(_lib.lib().fsw_conv_fused_lds_bytes(emb.nSlices, 1 if emb.encode_total_mass else 0)) <= 64 * 1024
+
+    def _fused_weight(self):
+        """(Wq, W2) of the first Linear layer W = [W1 | W2]: W1^T packed for 16-byte MFMA operand loads
+        (layout: include/fsw_hip.h, fsw_conv_fused_f32) and W2 contiguous; cached until the weight changes."""
+        lin = self.mlp[0]
+        key = (lin.weight.data_ptr(), lin.weight._version, tuple(lin.weight.shape))
+        cache = getattr(self, '_wt_cache', None)
+        if cache is None or cache[0] != key:
+            W = lin.weight.detach()
+            Hout, E = W.shape[0], self.embed_dim
+            Kp, ldw = (E + 7) // 8 * 8, (Hout + 31) // 32 * 32
+            wpad = torch.zeros((ldw, Kp), dtype=W.dtype, device=W.device)
+            wpad[:Hout, :E] = W[:, :E]
+            wq = wpad.view(ldw, Kp // 8, 4, 2).permute(1, 0, 3, 2).contiguous()     # [g][j][h][i] = W1[j][8g + 2i + h]
+            w2 = W[:, E:].contiguous() if self.concat_self else None
+            self._wt_cache = (key, wq, w2)
+        return self._wt_cache[1], self._wt_cache[2]
+
+    def _fused_linear(self, graph, prepared, scale, wq, y):
+        L = _lib.lib()
+        emb = self.fsw_embed
+        lin = self.mlp[0]
+        act, slope, next_module = 0, 0.0, 1
+        if len(self.mlp) > 1 and isinstance(self.mlp[1], torch.nn.LeakyReLU):
+            act, slope, next_module = 2, float(self.mlp[1].negative_slope), 2
+        elif len(self.mlp) > 1 and isinstance(self.mlp[1], torch.nn.ReLU):
+            act, next_module = 1, 2
+        has_mass = 1 if emb.encode_total_mass else 0
+        bias = emb.bias.detach() if emb.enable_bias else None
+        a = emb.make_args(graph, prepared["stats"], prepared["Xp"], prepared["ldp"], emb.freqs.detach(), emb.nSlices,
+                          prepared["table"], None, 0, bias.data_ptr() if bias is not None else None, scale, has_mass)
+        rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1],
+                                  lin.bias.data_ptr() if lin.bias is not None else None, lin.out_features,
+                                  1 if self.concat_self else 0, act, slope, y.data_ptr(), y.stride(0),
+                                  torch.cuda.current_stream(y.device).cuda_stream)
+        _lib.check(rc, "fsw_conv_fused_f32")
+        return next_module
 
     def enable_slice_parallel(self, group=None, enabled=True):
         """Shard the slice axis of the embedding over the ranks of `group` (dist.py); one all-gather per forward."""

@@ -300,7 +300,73 @@ class FSW_embedding(nn.Module):
         return out.reshape(out_shape + (self.d_out,))
 
     # ------------------------------------------------------------------------------------------------
-    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None):
+    def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):
+        """Projection of all slices + (unit weights) coefficient table + the one device->host stats read.
+
+        linear2 = (W2 [H2, d_in] contiguous, b2 [H2] or None, Y [n, H2]): the projection GEMM also writes
+        Y = X . W2^T + b2, the vertex-feature half of FSW_conv's first Linear layer (csrc/conv_fused.hip).
+
+        Returns a dict that embed_into(prepared=...) or FSW_conv's fused Linear path consume.  Input validation
+        (reference fsw_embedding.py:652-703) happens here: the kernels set flag bits, the host reads them once.
+        """
+        L = _lib.lib()
+        dev = X.device
+        S = self.nSlices
+        assert X.is_contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ldp = _round_up(S, 64)
+        Xp = torch.empty((X.shape[0], ldp), dtype=torch.float32, device=dev)
+        V = self.projVecs.detach()
+        if linear2 is not None:
+            W2, b2, Y2 = linear2
+            assert x_copy is None and W2.is_contiguous() and W2.shape[1] == self.d_in and Y2.stride(1) == 1
+            rc = L.fsw_project_linear_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(V), S, V.stride(0),
+                                          _lib.ptr(Xp), ldp, _lib.ptr(W2), W2.shape[0], W2.stride(0), _lib.ptr(b2),
+                                          _lib.ptr(Y2), Y2.stride(0), _lib.ptr(graph.stats_dev), stream)
+        else:
+            rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(V), S, V.stride(0), _lib.ptr(Xp),
+                                   ldp, _lib.ptr(x_copy), x_copy.stride(0) if x_copy is not None else 0,
+                                   _lib.ptr(graph.stats_dev), stream)
+        _lib.check(rc, "fsw_project_f32")
+        unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0
+        table = None
+        if unit_fast:
+            table = torch.empty((int(L.fsw_unit_table_rows(_lib.REG_MAX_DEG)), ldp), dtype=torch.float32, device=dev)
+            rc = L.fsw_unit_coeff_table(_lib.ptr(self.freqs.detach()), S, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
+            _lib.check(rc, "fsw_unit_coeff_table")
+        st = self._checked_stats(graph)
+        return {"Xp": Xp, "ldp": ldp, "table": table, "stats": st, "unit_fast": unit_fast}
+
+    @staticmethod
+    def _checked_stats(graph):
+        st = graph.stats()
+        if fsw_embedding_basic_safety_checks:
+            fl = st[_lib.STAT_FLAGS]
+            assert not (fl & _lib.FLAG_INDEX_RANGE), "adjacency index out of range"
+            assert not (fl & _lib.FLAG_X_NONFINITE), "The entries of X cannot contain NaNs or infs"
+            assert not (fl & _lib.FLAG_W_NONFINITE), "All entries of W must be finite"
+            assert not (fl & _lib.FLAG_W_NEGATIVE), "All entries of W must be nonnegative"
+        return st
+
+    def make_args(self, graph, st, Xp, ldp, freqs, S, table, out_ptr, ldo, bias_ptr, out_scale, has_mass, scratch=None):
+        a = _lib.EmbedArgs()
+        a.rowptr, a.col = graph.rowptr.data_ptr(), graph.col.data_ptr()
+        a.w = graph.w.data_ptr() if graph.w is not None else None
+        a.perm, a.bin_start, a.num_rows = graph.perm.data_ptr(), graph.bin_start.data_ptr(), graph.num_rows
+        a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, freqs.data_ptr(), S, float(self.total_mass_pad_thresh)
+        a.unit_table, a.ldt = (table.data_ptr() if table is not None else None), ldp
+        a.out, a.ldo, a.bias = out_ptr, ldo, bias_ptr
+        a.out_scale, a.has_mass = float(out_scale), has_mass
+        a.mass_fn = _MASS_FN[self.total_mass_encoding_function]
+        a.mass_scale = self._mass_scale_host() if self.encode_total_mass else 1.0
+        a.num_reg_rows, a.num_lds_rows = st[_lib.STAT_NUM_REG], st[_lib.STAT_NUM_LDS]
+        a.num_global_rows, a.num_zero_rows = st[_lib.STAT_NUM_GLOBAL], st[_lib.STAT_NUM_ZERO]
+        a.max_degree = st[_lib.STAT_MAX_DEGREE]
+        a.scratch = scratch.data_ptr() if scratch is not None else None
+        a.scratch_bytes = scratch.numel() if scratch is not None else 0
+        return a
+
+    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None, prepared=None):
         """Writes out_scale * E(X, graph) into the left columns of `out` (row stride out.stride(0)).
 
         X [num_cols, d_in] float32 contiguous; out [num_rows, >= width] float32 with unit inner stride, where
@@ -332,61 +398,46 @@ class FSW_embedding(nn.Module):
         bias = self.bias.detach() if (self.enable_bias and plain) else None
         if bias is not None and partial:
             bias = torch.cat([bias[:has_mass], bias[has_mass + ka:has_mass + kb]])
-        mass_scale = self._mass_scale_host() if self.encode_total_mass else 1.0
         unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0
 
         step = S if (serialize_num_slices is None or serialize_num_slices >= S) else int(serialize_num_slices)
         assert step >= 1, 'serialize_num_slices must be None or a positive integer'
-        ldp = _round_up(step, 64)
-        Xp = torch.empty((X.shape[0], ldp), dtype=torch.float32, device=dev)
+        if prepared is not None:
+            assert step == S and not partial, 'a prepared projection covers all slices in one chunk'
+            ldp, Xp, table, st = prepared["ldp"], prepared["Xp"], prepared["table"], prepared["stats"]
+        else:
+            ldp = _round_up(step, 64)
+            Xp = torch.empty((X.shape[0], ldp), dtype=torch.float32, device=dev)
+            table = None
+            if unit_fast:
+                table = torch.empty((int(L.fsw_unit_table_rows(_lib.REG_MAX_DEG)), ldp), dtype=torch.float32, device=dev)
+            st = None
         V = self.projVecs.detach()[ka:kb]
         freqs = self.freqs.detach()[ka:kb]
-        table = None
-        if unit_fast:
-            table = torch.empty((int(L.fsw_unit_table_rows(_lib.REG_MAX_DEG)), ldp), dtype=torch.float32, device=dev)
-        st = scratch = None
+        scratch = None
         for k0 in range(0, S, step):
             k1 = min(S, k0 + step)
             Sc = k1 - k0
-            Vc = V[k0:k1]
-            rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
-                                   _lib.ptr(Xp), ldp, _lib.ptr(x_copy) if k0 == 0 else None,
-                                   x_copy.stride(0) if x_copy is not None else 0,
-                                   _lib.ptr(graph.stats_dev) if k0 == 0 else None, stream)
-            _lib.check(rc, "fsw_project_f32")
-            if st is None:
-                # one device->host read per forward: validation flags (fused into the kernels) + degree classes
-                st = graph.stats()
-                if fsw_embedding_basic_safety_checks:
-                    fl = st[_lib.STAT_FLAGS]
-                    assert not (fl & _lib.FLAG_INDEX_RANGE), "adjacency index out of range"
-                    assert not (fl & _lib.FLAG_X_NONFINITE), "The entries of X cannot contain NaNs or infs"
-                    assert not (fl & _lib.FLAG_W_NONFINITE), "All entries of W must be finite"
-                    assert not (fl & _lib.FLAG_W_NEGATIVE), "All entries of W must be nonnegative"
-                if st[_lib.STAT_NUM_GLOBAL] > 0:
-                    scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=dev)
             fc = freqs[k0:k1]
-            if unit_fast:
-                rc = L.fsw_unit_coeff_table(_lib.ptr(fc), Sc, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
-                _lib.check(rc, "fsw_unit_coeff_table")
+            if prepared is None:
+                Vc = V[k0:k1]
+                rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
+                                       _lib.ptr(Xp), ldp, _lib.ptr(x_copy) if k0 == 0 else None,
+                                       x_copy.stride(0) if x_copy is not None else 0,
+                                       _lib.ptr(graph.stats_dev) if k0 == 0 else None, stream)
+                _lib.check(rc, "fsw_project_f32")
+                if unit_fast:
+                    rc = L.fsw_unit_coeff_table(_lib.ptr(fc), Sc, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
+                    _lib.check(rc, "fsw_unit_coeff_table")
+            if st is None:
+                st = self._checked_stats(graph)   # one device->host read per forward (flags + degree classes)
+            if scratch is None and st[_lib.STAT_NUM_GLOBAL] > 0:
+                scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=dev)
             first = (k0 == 0)
             hm = has_mass if first else 0          # the first chunk also writes the total-mass column
             col0 = 0 if first else has_mass + k0   # first destination column of this chunk
-            a = _lib.EmbedArgs()
-            a.rowptr, a.col = graph.rowptr.data_ptr(), graph.col.data_ptr()
-            a.w = graph.w.data_ptr() if graph.w is not None else None
-            a.perm, a.bin_start, a.num_rows = graph.perm.data_ptr(), graph.bin_start.data_ptr(), graph.num_rows
-            a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, fc.data_ptr(), Sc, float(self.total_mass_pad_thresh)
-            a.unit_table, a.ldt = (table.data_ptr() if table is not None else None), ldp
-            a.out, a.ldo = out.data_ptr() + 4 * col0, out.stride(0)
-            a.bias = (bias.data_ptr() + 4 * col0) if bias is not None else None
-            a.out_scale, a.has_mass = float(out_scale), hm
-            a.mass_fn, a.mass_scale = _MASS_FN[self.total_mass_encoding_function], mass_scale
-            a.num_reg_rows, a.num_lds_rows = st[_lib.STAT_NUM_REG], st[_lib.STAT_NUM_LDS]
-            a.num_global_rows, a.num_zero_rows = st[_lib.STAT_NUM_GLOBAL], st[_lib.STAT_NUM_ZERO]
-            a.max_degree = st[_lib.STAT_MAX_DEGREE]
-            a.scratch = scratch.data_ptr() if scratch is not None else None
-            a.scratch_bytes = scratch.numel() if scratch is not None else 0
+            a = self.make_args(graph, st, Xp, ldp, fc, Sc, table, out.data_ptr() + 4 * col0, out.stride(0),
+                               (bias.data_ptr() + 4 * col0) if bias is not None else None, out_scale, hm, scratch)
             rc = L.fsw_embed_f32(ctypes.byref(a), stream)
             _lib.check(rc, "fsw_embed_f32")
 

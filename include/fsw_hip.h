@@ -138,6 +138,27 @@ typedef struct {
 size_t fsw_embed_scratch_bytes(int64_t max_degree);
 int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
 
+/* ---- FSW_conv fast path: embedding fused with the first Linear layer of the MLP ---------------------
+ * Y[i, :] = act( [ out_scale * E(N(i)) , x_i ] . W^T + b ),  W = [W1 | W2]  -- reference fsw_conv.py:355-362
+ * (self.fsw_embed -> torch.cat((mw*emb, vertex_features)) -> mlp[0] -> activation) without writing the
+ * embedding to HBM, in two calls:
+ *   fsw_project_linear_f32  the projection GEMM with a second output block Y2 = X . W2^T + b2 (the
+ *                           vertex-feature half of the Linear layer; W2 [H2, ldw2] row-major);
+ *   fsw_conv_fused_f32      neighbourhood kernel + E . W1^T on the fp32 matrix cores; with y_accumulate
+ *                           != 0 it adds the row of Y written by the first call (else lin_bias), applies
+ *                           the activation (0 none, 1 relu, 2 leaky relu with `slope`) and stores Y [n, ldy].
+ * Preconditions of fsw_conv_fused_f32: unit weights (args->w == NULL), tau <= 1, no row above
+ * FSW_REG_MAX_DEG (args->num_lds_rows == num_global_rows == 0), fsw_conv_fused_lds_bytes() <= 64 KiB.
+ * args->out / ldo are ignored.  Wq: W1^T packed for 16-byte operand loads, zero padded:
+ *   Wq[((g*ldw + j)*8) + 4*h + i] = W1[j][8g + 2i + h],  g < ceil(K/8), j < ldw (Hout rounded up to 32),
+ *   K = has_mass + S, h in {0,1}, i in {0..3}; 16-byte aligned.                                        */
+size_t fsw_conv_fused_lds_bytes(int S, int has_mass);
+int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
+                           float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
+                           int64_t ldy2, int32_t* stats, fsw_stream_t stream);
+int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
+                       int y_accumulate, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
+
 /* ---- stand-alone segmented cumulative sum --------------------------------------------------------
  * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of
  * values restarted wherever consecutive segment ids differ, single pass (decoupled look-back),

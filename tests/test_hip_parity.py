@@ -193,7 +193,13 @@ def test_conv10k_config2(dev):
     assert relerr(np.linalg.norm(emb.astype(np.float64), axis=0), g["emb_colnorm_f64"]) < TOL
     assert np.array_equal(emb[:, 0], g["in_degrees"])                       # degree column is exact
     y = y.cpu().numpy()
-    assert relerr(y[rows], g["conv_rows_f64"]) < 2e-5                        # + one fp32 GEMM (stock torch)
+    assert conv._fusable()                                                   # default FSW_conv -> fused Linear kernel
+    assert relerr(y[rows], g["conv_rows_f64"]) < TOL
+    conv.fuse_linear = False                                                 # unfused kernels + stock torch Linear
+    with torch.no_grad():
+        y2 = conv(X, ei).cpu().numpy()
+    assert relerr(y2[rows], g["conv_rows_f64"]) < 2e-5
+    assert relerr(y2, y) < 2e-6
     # not worse than the reference's own float32 path measured against its float64 path
     assert relerr(emb[rows], g["emb_rows_f64"]) <= 1.5 * relerr(g["emb_rows_f32"], g["emb_rows_f64"]) + 1e-6
 

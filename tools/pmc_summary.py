@@ -28,8 +28,9 @@ def main():
     for k in sorted(fetch, key=lambda k: -fetch[k])[:12]:
         f, w = fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
         rows.append({"kernel": k[:80], "fetch_raw_bytes": f, "write_bytes": w, "hbm_bytes_corrected": 2 * f + w})
-        if "k_embed_reg_unit" in k:
-            out["k_embed_reg_unit_hbm_bytes_per_launch"] = 2 * f + w
+        for name in ("k_embed_reg_unit", "k_conv_fused_unit", "k_project", "k_rs_downsweep"):
+            if name in k:
+                out.setdefault(name + "_hbm_bytes_per_launch", 2 * f + w)
     out["kernels"] = rows
     dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic_latest.json"
     json.dump(out, open(dst, "w"), indent=1)
