@@ -87,9 +87,10 @@ def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
     graph = conv.build_graph(ei, n)
     fused = conv._fusable()
     y = torch.empty((n, conv.mlp[0].out_features), dtype=torch.float32, device=dev)
+    yin = torch.empty_like(y)
     if fused:
         wq, w2 = conv._fused_weight()
-        lin2 = (w2, conv.mlp[0].bias.detach(), y)
+        lin2 = (w2, conv.mlp[0].bias.detach(), yin)
     prepared = emb.prepare(x, graph, linear2=lin2 if fused else None)
     st = prepared["stats"]
     assert st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0, "config 3 is expected to sit on the register path"
@@ -118,7 +119,7 @@ def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
     edges = int(graph.rowptr[-1])
     gather_bytes = 4.0 * edges * S + 4.0 * edges + 8.0 * n        # Xp gather + col + rowptr/perm
     if fused:
-        ms["conv_fused_unit"] = timed_ms(lambda: conv._fused_linear(graph, prepared, 1.0, wq, y), reps, dev)
+        ms["conv_fused_unit"] = timed_ms(lambda: conv._fused_linear(graph, prepared, 1.0, wq, yin, y), reps, dev)
         kernel, kms = "k_conv_fused_unit", ms["conv_fused_unit"]
         # + Y (= x . W2^T + b from the projection kernel) read once and written once (packed W1^T, 0.13 MB, stays in L2)
         alg_bytes = gather_bytes + 8.0 * n * conv.mlp[0].out_features

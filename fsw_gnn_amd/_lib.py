@@ -40,7 +40,7 @@ _SIGNATURES = {
     "fsw_arch": (ctypes.c_char_p, []),
     "fsw_last_error": (ctypes.c_char_p, []),
     "fsw_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),
-    "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_project_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_unit_table_rows": (c_sz, [ctypes.c_int]),
     "fsw_unit_coeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
@@ -48,8 +48,8 @@ _SIGNATURES = {
     "fsw_embed_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp]),
     "fsw_conv_fused_lds_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
     "fsw_project_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64,
-                                              c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, ctypes.c_int,
+                                              c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, c_vp, c_i64,
                                           ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     "fsw_segcumsum_workspace_bytes": (c_sz, [c_i64]),
     "fsw_segcumsum": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_sz, c_vp]),

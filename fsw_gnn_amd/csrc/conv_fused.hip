@@ -22,6 +22,7 @@
 //   phase 3  + Y row (x . W2^T + b), activation, rows scattered back to Y by node id
 // HBM traffic per forward drops by ~3.6 GB at BASELINE config 3 (no E write, no E/x re-read, no concat, no
 // activation pass).
+#include <stdlib.h>
 #include "fsw_common.h"
 #include "sortnet.h"
 
@@ -48,7 +49,8 @@ struct FusedArgs {
   const float* Wq;  // packed W1^T: [Kp/8][ldw][8], zero padded (Kp = K rounded up to 8, ldw = Hout rounded up to 32)
   int64_t ldw;
   const float* lin_bias;  // [Hout] or null; used only when y_accumulate == 0
-  int y_accumulate;       // 1: Y already holds x . W2^T + b (written by the projection kernel)
+  const float* Yin;       // [n][ldyin] x . W2^T + b in perm order (written by the projection kernel) or null
+  int64_t ldyin;
   int Hout;
   int act;  // 0 none, 1 relu, 2 leaky relu
   float slope;
@@ -102,7 +104,8 @@ __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int 
   X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
   X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
-__global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
+template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0>  // ABL: timing experiments only (tools/exp_fused.py)
+__global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;                                                        // [kFusedRows][ldh]
   int* nodeS = reinterpret_cast<int*>(smem + kFusedRows * a.ldh);         // [kFusedRows]
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
   int D, p = 0, pe = 0;
   {
     int b = blockIdx.x;
-    for (D = FSW_REG_MAX_DEG; D >= 0; --D) {
+    for (D = DHI; D >= DLO; --D) {
       const int lo = a.bin_start[D], hi = a.bin_start[D + 1];
       const int nb = (hi - lo + kFusedRows - 1) / kFusedRows;
       if (b < nb) {
@@ -121,12 +124,13 @@ __global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
       }
       b -= nb;
     }
-    if (D < 0) return;
+    if (D < DLO) return;
   }
   const int nrows = pe - p;
   const int wv = wave_id();
   const int lane = lane_id();
   const int K = a.has_mass + a.S;  // embedding width = K of the fused product
+  const int fr = lane & 31, fh = lane >> 5;
 
   // zero the K padding column(s) and the unused rows of H, record node ids, mass column
   if (threadIdx.x < kFusedRows) {
@@ -140,9 +144,9 @@ __global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
   const int nchunks = (a.S + kWave - 1) / kWave;
   for (int chunk = wv; chunk < nchunks; chunk += 4) {
     switch (D) {
-#define X(d)                                   \
-  case d:                                      \
-    fused_embed_rows<d>(a, p, nrows, H, chunk); \
+#define X(d)                                                  \
+  case d:                                                     \
+    if constexpr (d >= DLO && d <= DHI) fused_embed_rows<d>(a, p, nrows, H, chunk); \
     break;
       FSW_CASES_0_32(X)
 #undef X
@@ -150,56 +154,78 @@ __global__ void __launch_bounds__(256) k_conv_fused_unit(const FusedArgs a) {
         break;
     }
   }
+  // Rows of Yin (= x . W2^T + b, stored by the projection kernel in perm order, so this workgroup's 32 rows are one
+  // contiguous run) that this wave's first output slab needs.  Issued after phase 1 (registers are free again) and before
+  // the barrier, so the reads are in flight while the workgroup's other waves finish their rows.
+  float yin[16];
+  {
+    const int j = wv * 32 + fr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;     // C/D map of the 32x32 MFMA
+      yin[r] = 0.f;
+      if ((ABL & 2) == 0 && a.Yin && row < nrows && j < a.Hout) yin[r] = a.Yin[(int64_t)(p + row) * a.ldyin + j];
+    }
+  }
+
   __syncthreads();
 
   // phase 2 + 3: Y tile = H . W1^T, one 32-column slab per wave and iteration
-  const int fr = lane & 31, fh = lane >> 5;
   const int nslabs = (a.Hout + 31) / 32;
   const int ngroups = a.Kp >> 3;
+  constexpr int kPrefetch = 8;   // 16-byte W loads in flight per wave (they queue behind the CU's HBM gathers)
   for (int slab = wv; slab < nslabs; slab += 4) {
     const int j0 = slab * 32;
+    const int j = j0 + fr;
+    if (slab != wv) {            // later slabs of wide layers: Y rows loaded here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int node = nodeS[(r & 3) + 8 * (r >> 2) + 4 * fh];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        yin[r] = (a.Yin && node >= 0 && j < a.Hout) ? a.Yin[(int64_t)(p + row) * a.ldyin + j] : 0.f;
+      }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* hp = H + fr * a.ldh + fh;
-    const float4* wq = reinterpret_cast<const float4*>(a.Wq) + ((int64_t)(j0 + fr) * 2 + fh);
-    const int64_t gstride = a.ldw * 2;  // float4 units between consecutive k-groups
-    auto loadw = [&](int g) { return wq[(int64_t)min(g, ngroups - 1) * gstride]; };
-    auto mma4 = [&](int g, const float4& bq) {
-      const float* h = hp + 8 * g;
+    // packed W1^T: group g of this lane at wq[g * gstride]; the host pads kPrefetch zero groups past the end
+    const float4* wq = reinterpret_cast<const float4*>(a.Wq) + ((int64_t)j * 2 + fh);
+    const int64_t gstride = a.ldw * 2;
+    auto mma4 = [&](const float* h, const float4& bq) {
+      if constexpr (ABL & 1) { asm volatile("" ::"v"(bq.x), "v"(bq.y), "v"(bq.z), "v"(bq.w)); return; }
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], bq.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], bq.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[4], bq.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[6], bq.w, acc, 0, 0, 0);
     };
-    // W1^T comes from L2 while every other wave of the CU is streaming gathers from HBM: ~1 us per load under load.
-    // Keep kPrefetch groups (one 16-byte load each, four MFMAs = 256 cycles) in flight per wave.
-    constexpr int kPrefetch = 8;
     float4 bq[kPrefetch];
 #pragma unroll
-    for (int u = 0; u < kPrefetch; ++u) bq[u] = loadw(u);
-    for (int g0 = 0; g0 < ngroups; g0 += kPrefetch) {
+    for (int u = 0; u < kPrefetch; ++u) bq[u] = wq[u * gstride];
+    wq += kPrefetch * gstride;
+    int g0 = 0;
+    for (; g0 + kPrefetch <= ngroups; g0 += kPrefetch) {
 #pragma unroll
       for (int u = 0; u < kPrefetch; ++u) {
-        if (g0 + u < ngroups) mma4(g0 + u, bq[u]);
-        bq[u] = loadw(g0 + u + kPrefetch);
+        mma4(hp + 8 * (g0 + u), bq[u]);
+        bq[u] = wq[u * gstride];
       }
+      wq += kPrefetch * gstride;
     }
+#pragma unroll
+    for (int u = 0; u < kPrefetch; ++u)
+      if (g0 + u < ngroups) mma4(hp + 8 * (g0 + u), bq[u]);
 
-    const int j = j0 + fr;
     if (j < a.Hout) {
-      const float lb = (!a.y_accumulate && a.lin_bias) ? a.lin_bias[j] : 0.f;
+      const float lb = (!a.Yin && a.lin_bias) ? a.lin_bias[j] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
-        const int node = nodeS[row];
+        const int node = nodeS[(r & 3) + 8 * (r >> 2) + 4 * fh];
         if (node >= 0) {
-          float* yp = a.Y + (int64_t)node * a.ldy + j;
-          float y = acc[r] + lb;
-          if (a.y_accumulate) y += *yp;
+          float y = acc[r] + lb + yin[r];
           if (a.act == 1) y = fmaxf(y, 0.f);
           else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
-          *yp = y;
+          if ((ABL & 4) == 0 || y == 12345.f) a.Y[(int64_t)node * a.ldy + j] = y;
         }
       }
     }
@@ -217,7 +243,8 @@ extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
 }
 
 extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
-                                  int y_accumulate, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream_) {
+                                  const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy,
+                                  fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(args && Wq && Y, "fsw_conv_fused_f32: null pointer");
   const fsw_embed_args& e = *args;
@@ -226,6 +253,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   FSW_REQUIRE(e.num_lds_rows == 0 && e.num_global_rows == 0,
               "fsw_conv_fused_f32: rows with in-degree > %d must take the unfused path", FSW_REG_MAX_DEG);
   FSW_REQUIRE(e.S >= 1 && e.ldp >= e.S && e.ldt >= e.S && (e.has_mass == 0 || e.has_mass == 1), "fsw_conv_fused_f32: bad sizes");
+  FSW_REQUIRE(!Yin || ldyin >= Hout, "fsw_conv_fused_f32: bad Yin stride");
   FSW_REQUIRE(Hout >= 1 && ldy >= Hout && ldw >= ((Hout + 31) / 32) * 32 && ldw % 32 == 0, "fsw_conv_fused_f32: bad output sizes");
   FSW_REQUIRE(((uintptr_t)Wq & 15) == 0, "fsw_conv_fused_f32: Wq must be 16-byte aligned");
   FSW_REQUIRE(act >= 0 && act <= 2, "fsw_conv_fused_f32: act must be 0 (none), 1 (relu) or 2 (leaky relu)");
@@ -235,12 +263,24 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   a.rowptr = e.rowptr; a.col = e.col; a.perm = e.perm; a.bin_start = e.bin_start;
   a.Xp = e.Xp; a.ldp = e.ldp; a.S = e.S; a.table = e.unit_table; a.ldt = e.ldt;
   a.bias = e.bias; a.out_scale = e.out_scale; a.has_mass = e.has_mass; a.mass_fn = e.mass_fn; a.mass_scale = e.mass_scale;
-  a.Wq = Wq; a.ldw = ldw; a.lin_bias = lin_bias; a.y_accumulate = y_accumulate ? 1 : 0; a.Hout = Hout; a.act = act; a.slope = slope;
+  a.Wq = Wq; a.ldw = ldw; a.lin_bias = lin_bias; a.Yin = Yin; a.ldyin = ldyin; a.Hout = Hout; a.act = act; a.slope = slope;
   a.Y = Y; a.ldy = ldy;
   a.Kp = (e.has_mass + e.S + 7) & ~7;
   a.ldh = a.Kp | 1;
+  // two launches: long rows first (more registers per wave), then degrees 0..16 at higher occupancy
   const int64_t nblocks = ceil_div(e.num_rows, kFusedRows) + FSW_REG_MAX_DEG + 1;
-  k_conv_fused_unit<<<(unsigned)nblocks, 256, lds, stream>>>(a);
+#ifdef FSW_ABLATION
+  const char* abl_env = getenv("FSW_FUSED_ABL");
+  const int abl = abl_env ? atoi(abl_env) : 0;
+#define FSW_ABL_CASE(v)                                                                   \
+  if (abl == v) {                                                                         \
+    k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4, v><<<(unsigned)nblocks, 256, lds, stream>>>(a); \
+    FSW_LAUNCH_CHECK();                                                                   \
+    return 0;                                                                             \
+  }
+  FSW_ABL_CASE(1) FSW_ABL_CASE(2) FSW_ABL_CASE(4) FSW_ABL_CASE(6) FSW_ABL_CASE(7)
+#endif
+  k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4><<<(unsigned)nblocks, 256, lds, stream>>>(a);
   FSW_LAUNCH_CHECK();
   return 0;
 }

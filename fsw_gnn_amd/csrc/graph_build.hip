@@ -344,7 +344,8 @@ __global__ void k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __
 }
 
 __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ rowptr, int64_t n,
-                                                  int32_t* __restrict__ bin_cursor, int32_t* __restrict__ perm) {
+                                                  int32_t* __restrict__ bin_cursor, int32_t* __restrict__ perm,
+                                                  int32_t* __restrict__ invperm) {
   __shared__ int lcount[FSW_NUM_BINS];
   __shared__ int lbase[FSW_NUM_BINS];
   if (threadIdx.x < FSW_NUM_BINS) lcount[threadIdx.x] = 0;
@@ -358,7 +359,10 @@ __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ ro
   __syncthreads();
   if (threadIdx.x < FSW_NUM_BINS && lcount[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], lcount[threadIdx.x]);
   __syncthreads();
-  if (r < n) perm[lbase[bin] + rank] = (int32_t)r;
+  if (r < n) {
+    perm[lbase[bin] + rank] = (int32_t)r;
+    if (invperm) invperm[r] = lbase[bin] + rank;
+  }
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------
@@ -447,7 +451,7 @@ extern "C" size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges)
 
 extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
                                int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* perm,
-                               int32_t* bin_start, int32_t* stats, void* workspace, size_t workspace_bytes,
+                               int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace, size_t workspace_bytes,
                                fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) - 1 && num_cols >= 1 && num_cols < (1ll << 31) && num_edges >= 0 &&
@@ -475,7 +479,7 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
   FSW_LAUNCH_CHECK();
   k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
   FSW_LAUNCH_CHECK();
-  k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm);
+  k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
   FSW_LAUNCH_CHECK();
   return 0;
 }

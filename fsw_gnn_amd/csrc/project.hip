@@ -8,6 +8,7 @@
 //
 // Tiling: 256 threads = 4 waves as 2x2; workgroup tile 128 rows x 128 slices, K step 32 through LDS;
 // each wave owns a 64x64 sub-tile = 2x2 MFMA blocks of 32x32 (64 accumulator registers).
+#include <stdlib.h>
 #include <algorithm>
 #include "fsw_common.h"
 
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
                                                  int64_t ldp, int32_t* __restrict__ stats, int nct,
                                                  float* __restrict__ x_copy, int64_t ld_copy,
                                                  const float* __restrict__ W2, int H2, int64_t ldw2,
-                                                 const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2) {
+                                                 const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
+                                                 const int32_t* __restrict__ row_map) {
   __shared__ float As[PBM][PLD];
   __shared__ float Bs[PBN][PLD];
   const int ct = blockIdx.x % nct;
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(256) k_project(const float* __restrict__ X, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gr = row0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (gr < n) dst[gr * ld] = acc[i][j][r] + add;
+        if (gr < n) dst[((second && row_map) ? (int64_t)row_map[gr] : gr) * ld] = acc[i][j][r] + add;
       }
     }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
                                                     float* __restrict__ x_copy, int64_t ld_copy,
                                                     const float* __restrict__ W2, int H2, int64_t ldw2,
                                                     const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
-                                                    int64_t ntiles, int nslab_waves) {
+                                                    const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves) {
   __shared__ float As[2][BS_ROWS][BS_LD];
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
@@ -224,7 +226,154 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (gr < n) dst[gr * ldd] = acc[r] + add;
+        if (gr < n) dst[((second && row_map) ? (int64_t)row_map[gr] : gr) * ldd] = acc[r] + add;
+      }
+    }
+    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
+}
+
+// ---- bf16x3 variant: fp32-accurate product on the bf16 matrix cores ------------------------------------------------
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) carries 24 significand bits, the same
+// for the weights; the product keeps the six terms down to 2^-16 relative (x1 v1, x1 v2, x2 v1, x1 v3, x2 v2, x3 v1),
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and drops terms below 2^-24.  Six bf16 MFMAs at 16x
+// the fp32 MFMA rate = 2.7x the throughput of the exact-fp32 kernel above at the same ~1e-7 accuracy (bf16 keeps
+// fp32's exponent range, so no scaling is needed).  Same B-stationary structure as k_project_bs: every wave keeps
+// the three bf16 planes of its 32-column weight slab in registers, X tiles are split once when they enter LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int B3_LD = 136;  // bf16 per LDS row: 128 + 8 (16-byte pad)
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  const float r = v - (float)a;
+  b = (__bf16)r;
+  c = (__bf16)(r - (float)b);
+}
+
+template <int KS>
+__global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                     const float* __restrict__ V, int S, int64_t ldv,
+                                                     float* __restrict__ Xp, int64_t ldp, int32_t* __restrict__ stats,
+                                                     float* __restrict__ x_copy, int64_t ld_copy,
+                                                     const float* __restrict__ W2, int H2, int64_t ldw2,
+                                                     const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
+                                                     const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BS_ROWS][B3_LD];
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int N = S + H2;
+  const int slab = blockIdx.y * nslab_waves + wv;
+  const bool slab_active = wv < nslab_waves && slab * 32 < N;
+  const int c = slab_active ? slab * 32 + fr : N;
+
+  // weight slab as MFMA B operands: lane (fr, fh), k-step s holds W[c][16 s + 8 fh + j], j = 0..7, in three planes
+  bf16x8 bw[3][KS];
+  {
+    const float* wrow = c < S ? V + (int64_t)c * ldv : (c < N ? W2 + (int64_t)(c - S) * ldw2 : nullptr);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * fh + j;
+        const float v = (wrow && k < d) ? wrow[k] : 0.f;
+        __bf16 h1, h2, h3;
+        split3(v, h1, h2, h3);
+        bw[0][s][j] = h1;
+        bw[1][s][j] = h2;
+        bw[2][s][j] = h3;
+      }
+  }
+  const bool second = c >= S;
+  float* dst = c < N ? (second ? Y2 + (c - S) : Xp + c) : nullptr;
+  const int64_t ldd = second ? ldy2 : ldp;
+  const float add = (second && b2 && c < N) ? b2[c - S] : 0.f;
+
+  for (int i = threadIdx.x; i < 2 * 3 * BS_ROWS * B3_LD / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(&As[0][0][0][0])[i] = 0u;
+  __syncthreads();
+
+  const int d4 = d >> 2;
+  const int per_tile = BS_ROWS * d4;
+  int nonfinite = 0;
+  auto load_tile = [&](int64_t tile, float4& q0, float4& q1) {
+    const int64_t row0 = tile * BS_ROWS;
+    q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    q1 = q0;
+    const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+    if (i0 < per_tile) {
+      const int r = i0 / d4, c4 = i0 - r * d4;
+      if (row0 + r < n) q0 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+    }
+    if (i1 < per_tile) {
+      const int r = i1 / d4, c4 = i1 - r * d4;
+      if (row0 + r < n) q1 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+    }
+  };
+  auto store_tile = [&](int buf, int64_t tile, const float4& q0, const float4& q1) {
+    const int64_t row0 = tile * BS_ROWS;
+    const int idx[2] = {(int)threadIdx.x, (int)(threadIdx.x + blockDim.x)};
+    const float4 q[2] = {q0, q1};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (idx[u] < per_tile) {
+        const int r = idx[u] / d4, c4 = idx[u] - r * d4;
+        const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          nonfinite |= !(fabsf(v[j]) <= 3.402823466e38f);
+          __bf16 h1, h2, h3;
+          split3(v[j], h1, h2, h3);
+          p1[j] = h1;
+          p2[j] = h2;
+          p3[j] = h3;
+          if (blockIdx.y == 0 && x_copy && row0 + r < n) x_copy[(row0 + r) * ld_copy + 4 * c4 + j] = v[j];
+        }
+        *reinterpret_cast<bf16x4*>(&As[buf][0][r][4 * c4]) = p1;
+        *reinterpret_cast<bf16x4*>(&As[buf][1][r][4 * c4]) = p2;
+        *reinterpret_cast<bf16x4*>(&As[buf][2][r][4 * c4]) = p3;
+      }
+    }
+  };
+
+  int64_t tile = blockIdx.x;
+  float4 q0, q1;
+  if (tile < ntiles) {
+    load_tile(tile, q0, q1);
+    store_tile(0, tile, q0, q1);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next, q0, q1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (slab_active) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][0][fr][16 * s + 8 * fh]);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[buf][1][fr][16 * s + 8 * fh]);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[buf][2][fr][16 * s + 8 * fh]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bw[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[2][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
+      }
+    }
+    if (dst) {
+      const int64_t row0 = tile * BS_ROWS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (gr < n) dst[((second && row_map) ? (int64_t)row_map[gr] : gr) * ldd] = acc[r] + add;
       }
     }
     if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
@@ -240,7 +389,7 @@ using namespace fsw;
 
 static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv, float* Xp,
                           int64_t ldp, float* x_copy, int64_t ld_copy, const float* W2, int H2, int64_t ldw2, const float* b2,
-                          float* Y2, int64_t ldy2, int32_t* stats, hipStream_t stream) {
+                          float* Y2, int64_t ldy2, const int32_t* row_map, int32_t* stats, hipStream_t stream) {
   FSW_REQUIRE(X && V && Xp, "fsw_project: null pointer");
   FSW_REQUIRE(!x_copy || ld_copy >= d, "fsw_project: ld_copy must be >= d");
   FSW_REQUIRE(n >= 1 && d >= 1 && S >= 1 && ldx >= d && ldv >= d && ldp >= S, "fsw_project: bad sizes n=%lld d=%d S=%d",
@@ -258,12 +407,21 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
     const int64_t ntiles = ceil_div(n, BS_ROWS);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, 256), (unsigned)ngroups);
     const int threads = std::max(nwaves, 8) * 64;
-#define FSW_LAUNCH_BS(KQ)                                                                                                \
-  k_project_bs<KQ><<<grid, threads, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, b2, \
-                                                 Y2, ldy2, ntiles, nwaves)
-    if (d <= 32) FSW_LAUNCH_BS(16);
-    else if (d <= 64) FSW_LAUNCH_BS(32);
-    else FSW_LAUNCH_BS(64);
+    // FSW_PROJECT_EXACT_FP32=1 selects the exact-fp32 MFMA kernel instead of the bf16x3 one (same accuracy class,
+    // 2.7x fewer matrix-core cycles); read once
+    static const bool exact = getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
+#define FSW_LAUNCH_BS(KERNEL, T)                                                                                          \
+  KERNEL<T><<<grid, threads, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, b2, Y2, \
+                                          ldy2, row_map, ntiles, nwaves)
+    if (exact) {
+      if (d <= 32) FSW_LAUNCH_BS(k_project_bs, 16);
+      else if (d <= 64) FSW_LAUNCH_BS(k_project_bs, 32);
+      else FSW_LAUNCH_BS(k_project_bs, 64);
+    } else {
+      if (d <= 32) FSW_LAUNCH_BS(k_project_bf3, 2);
+      else if (d <= 64) FSW_LAUNCH_BS(k_project_bf3, 4);
+      else FSW_LAUNCH_BS(k_project_bf3, 8);
+    }
 #undef FSW_LAUNCH_BS
     FSW_LAUNCH_CHECK();
     return 0;
@@ -273,23 +431,23 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
   FSW_REQUIRE(nblocks < (1ll << 31), "fsw_project: grid too large");
   if (vec)
     k_project<true><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy, W2, H2,
-                                                           ldw2, b2, Y2, ldy2);
+                                                           ldw2, b2, Y2, ldy2, row_map);
   else
     k_project<false><<<(unsigned)nblocks, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, nct, x_copy, ld_copy, W2, H2,
-                                                            ldw2, b2, Y2, ldy2);
+                                                            ldw2, b2, Y2, ldy2, row_map);
   FSW_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
                                float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream) {
-  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, x_copy, ld_copy, nullptr, 0, 0, nullptr, nullptr, 0, stats,
+  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, x_copy, ld_copy, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, stats,
                         reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
                                       float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
-                                      int64_t ldy2, int32_t* stats, fsw_stream_t stream) {
-  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, nullptr, 0, W2, H2, ldw2, b2, Y2, ldy2, stats,
+                                      int64_t ldy2, const int32_t* row_map, int32_t* stats, fsw_stream_t stream) {
+  return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, nullptr, 0, W2, H2, ldw2, b2, Y2, ldy2, row_map, stats,
                         reinterpret_cast<hipStream_t>(stream));
 }

@@ -173,7 +173,7 @@ class FSW_conv(_Base):
             deg = torch.zeros(num_vertices, device=src.device, dtype=torch.float32).scatter_add_(0, dst, w)
             ds = torch.sqrt(deg)
             w = w / ds[dst] / ds[src]
-        return build_csr(dst, src, w, num_vertices, num_vertices)
+        return build_csr(dst, src, w, num_vertices, num_vertices, want_invperm=self._fusable())
 
     def forward(self, vertex_features, edge_index, edge_features=None):
         """vertex_features [n, in_channels], edge_index [2, E] long -> [n, out_channels] (fsw_conv.py:331-369)."""
@@ -201,11 +201,12 @@ class FSW_conv(_Base):
             lin = self.mlp[0]
             wq, w2 = self._fused_weight()
             y = torch.empty((n, lin.out_features), dtype=x.dtype, device=x.device)
-            lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, y) if self.concat_self else None
+            yin = torch.empty_like(y) if self.concat_self else None      # x . W2^T + b in degree-bin row order
+            lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, yin) if self.concat_self else None
             prepared = emb_mod.prepare(x, graph, linear2=lin2)
             st = prepared["stats"]
             if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
-                next_module = self._fused_linear(graph, prepared, scale, wq, y)
+                next_module = self._fused_linear(graph, prepared, scale, wq, yin, y)
                 for m in self.mlp[next_module:]:
                     y = m(y)
                 return y
@@ -255,7 +256,7 @@ class FSW_conv(_Base):
         if cache is None or cache[0] != key:
             W = lin.weight.detach()
             Hout, E = W.shape[0], self.embed_dim
-            Kp, ldw = (E + 7) // 8 * 8, (Hout + 31) // 32 * 32
+            Kp, ldw = (E + 7) // 8 * 8 + 16 * 8, (Hout + 31) // 32 * 32     # + 16 zero groups: the kernel prefetches ahead
             wpad = torch.zeros((ldw, Kp), dtype=W.dtype, device=W.device)
             wpad[:Hout, :E] = W[:, :E]
             wq = wpad.view(ldw, Kp // 8, 4, 2).permute(1, 0, 3, 2).contiguous()     # [g][j][h][i] = W1[j][8g + 2i + h]
@@ -263,7 +264,7 @@ class FSW_conv(_Base):
             self._wt_cache = (key, wq, w2)
         return self._wt_cache[1], self._wt_cache[2]
 
-    def _fused_linear(self, graph, prepared, scale, wq, y):
+    def _fused_linear(self, graph, prepared, scale, wq, yin, y):
         L = _lib.lib()
         emb = self.fsw_embed
         lin = self.mlp[0]
@@ -278,7 +279,8 @@ class FSW_conv(_Base):
                           prepared["table"], None, 0, bias.data_ptr() if bias is not None else None, scale, has_mass)
         rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1],
                                   lin.bias.data_ptr() if lin.bias is not None else None, lin.out_features,
-                                  1 if self.concat_self else 0, act, slope, y.data_ptr(), y.stride(0),
+                                  yin.data_ptr() if yin is not None else None, yin.stride(0) if yin is not None else 0,
+                                  act, slope, y.data_ptr(), y.stride(0),
                                   torch.cuda.current_stream(y.device).cuda_stream)
         _lib.check(rc, "fsw_conv_fused_f32")
         return next_module

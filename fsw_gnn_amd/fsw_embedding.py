@@ -303,8 +303,9 @@ class FSW_embedding(nn.Module):
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):
         """Projection of all slices + (unit weights) coefficient table + the one device->host stats read.
 
-        linear2 = (W2 [H2, d_in] contiguous, b2 [H2] or None, Y [n, H2]): the projection GEMM also writes
-        Y = X . W2^T + b2, the vertex-feature half of FSW_conv's first Linear layer (csrc/conv_fused.hip).
+        linear2 = (W2 [H2, d_in] contiguous, b2 [H2] or None, Y2 [n, H2]): the projection GEMM also writes
+        Y2[graph.invperm[i]] = X[i] . W2^T + b2, the vertex-feature half of FSW_conv's first Linear layer in the
+        row order of the degree bins (csrc/conv_fused.hip reads it back as contiguous runs).
 
         Returns a dict that embed_into(prepared=...) or FSW_conv's fused Linear path consume.  Input validation
         (reference fsw_embedding.py:652-703) happens here: the kernels set flag bits, the host reads them once.
@@ -322,7 +323,7 @@ class FSW_embedding(nn.Module):
             assert x_copy is None and W2.is_contiguous() and W2.shape[1] == self.d_in and Y2.stride(1) == 1
             rc = L.fsw_project_linear_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(V), S, V.stride(0),
                                           _lib.ptr(Xp), ldp, _lib.ptr(W2), W2.shape[0], W2.stride(0), _lib.ptr(b2),
-                                          _lib.ptr(Y2), Y2.stride(0), _lib.ptr(graph.stats_dev), stream)
+                                          _lib.ptr(Y2), Y2.stride(0), _lib.ptr(graph.invperm), _lib.ptr(graph.stats_dev), stream)
         else:
             rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(V), S, V.stride(0), _lib.ptr(Xp),
                                    ldp, _lib.ptr(x_copy), x_copy.stride(0) if x_copy is not None else 0,

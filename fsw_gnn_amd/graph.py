@@ -17,10 +17,11 @@ class CSRGraph:
     stats_dev int32[NUM_STATS] (device) -- read back once per forward by `stats()`.
     """
 
-    def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev):
+    def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None):
         self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
         self.rowptr, self.col, self.w, self.perm, self.bin_start = rowptr, col, w, perm, bin_start
         self.stats_dev = stats_dev
+        self.invperm = invperm
         self._stats = None
 
     def stats(self):
@@ -42,7 +43,7 @@ class CSRGraph:
         return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
 
 
-def build_csr(recipients, senders, edge_w, num_rows, num_cols):
+def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False):
     """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights)."""
     L = _lib.lib()
     dev = recipients.device
@@ -60,13 +61,14 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols):
     col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     w = torch.empty(max(E, 1), dtype=torch.float32, device=dev) if edge_w is not None else None
     perm = torch.empty(num_rows, dtype=torch.int32, device=dev)
+    invperm = torch.empty(num_rows, dtype=torch.int32, device=dev) if want_invperm else None
     bin_start = torch.empty(_lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
     stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
     ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     rc = L.fsw_graph_build(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols,
-                           _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(bin_start),
+                           _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
                            _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
-    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats)
+    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, invperm)

@@ -75,11 +75,12 @@ const char* fsw_last_error(void); /* host string, valid until the next failing c
  *   edge_w             : float[num_edges] or NULL for unit weights
  *   rowptr int32[num_rows+1], col int32[num_edges], w float[num_edges] (ignored if edge_w NULL)
  *   perm int32[num_rows]  rows ordered by degree bin; bin_start int32[FSW_NUM_BINS+1] offsets into perm
+ *   invperm int32[num_rows] or NULL: position of every row in perm (perm[invperm[r]] == r)
  *   stats int32[FSW_NUM_STATS] (zeroed by this call)                                               */
 size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges);
 int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w,
                     int64_t num_edges, int64_t num_rows, int64_t num_cols,
-                    int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* bin_start,
+                    int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* invperm, int32_t* bin_start,
                     int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
 
 /* ---- projection: Xp[n, ldp] = X[n, ldx] . V[S, ldv]^T, fp32 MFMA (v_mfma_f32_32x32x2_f32) -------
@@ -143,21 +144,24 @@ int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
  * (self.fsw_embed -> torch.cat((mw*emb, vertex_features)) -> mlp[0] -> activation) without writing the
  * embedding to HBM, in two calls:
  *   fsw_project_linear_f32  the projection GEMM with a second output block Y2 = X . W2^T + b2 (the
- *                           vertex-feature half of the Linear layer; W2 [H2, ldw2] row-major);
- *   fsw_conv_fused_f32      neighbourhood kernel + E . W1^T on the fp32 matrix cores; with y_accumulate
- *                           != 0 it adds the row of Y written by the first call (else lin_bias), applies
- *                           the activation (0 none, 1 relu, 2 leaky relu with `slope`) and stores Y [n, ldy].
+ *                           vertex-feature half of the Linear layer; W2 [H2, ldw2] row-major).  Row i of
+ *                           the block is stored at Y2[row_map[i]] when row_map != NULL -- pass the graph's
+ *                           invperm so that every workgroup of the fused kernel reads one contiguous run;
+ *   fsw_conv_fused_f32      neighbourhood kernel + E . W1^T on the fp32 matrix cores; with Yin != NULL it
+ *                           adds row invperm-position p of Yin [n, ldyin] (else lin_bias), applies the
+ *                           activation (0 none, 1 relu, 2 leaky relu with `slope`) and stores Y [n, ldy].
  * Preconditions of fsw_conv_fused_f32: unit weights (args->w == NULL), tau <= 1, no row above
  * FSW_REG_MAX_DEG (args->num_lds_rows == num_global_rows == 0), fsw_conv_fused_lds_bytes() <= 64 KiB.
  * args->out / ldo are ignored.  Wq: W1^T packed for 16-byte operand loads, zero padded:
- *   Wq[((g*ldw + j)*8) + 4*h + i] = W1[j][8g + 2i + h],  g < ceil(K/8), j < ldw (Hout rounded up to 32),
- *   K = has_mass + S, h in {0,1}, i in {0..3}; 16-byte aligned.                                        */
+ *   Wq[((g*ldw + j)*8) + 4*h + i] = W1[j][8g + 2i + h],  g < ceil(K/8) + 16 (the tail groups are zero:
+ *   the kernel prefetches past the end), j < ldw (Hout rounded up to 32), K = has_mass + S, h in {0,1},
+ *   i in {0..3}; 16-byte aligned.                                                                      */
 size_t fsw_conv_fused_lds_bytes(int S, int has_mass);
 int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
                            float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
-                           int64_t ldy2, int32_t* stats, fsw_stream_t stream);
+                           int64_t ldy2, const int32_t* row_map, int32_t* stats, fsw_stream_t stream);
 int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
-                       int y_accumulate, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
+                       const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
 
 /* ---- stand-alone segmented cumulative sum --------------------------------------------------------
  * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of
