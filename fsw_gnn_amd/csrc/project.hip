@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
                                                     const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
                                                     const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves) {
   __shared__ float As[2][BS_ROWS][BS_LD];
+  __shared__ int rmap[2][BS_ROWS];
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
   };
   auto store_tile = [&](int buf, int64_t tile, const float4& q0, const float4& q1) {
     const int64_t row0 = tile * BS_ROWS;
+    if (row_map && threadIdx.x < BS_ROWS) rmap[buf][threadIdx.x] = row0 + threadIdx.x < n ? row_map[row0 + threadIdx.x] : 0;
     const int idx[2] = {(int)threadIdx.x, (int)(threadIdx.x + blockDim.x)};
     const float4 q[2] = {q0, q1};
 #pragma unroll
@@ -202,17 +204,21 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
     }
   };
 
+  // software pipeline, two tiles deep: registers hold tile t+1 (loaded during iteration t-1) and go to LDS at the top
+  // of iteration t; the HBM loads of tile t+2 are issued right after and have the whole iteration to land
   int64_t tile = blockIdx.x;
   float4 q0, q1;
   if (tile < ntiles) {
     load_tile(tile, q0, q1);
     store_tile(0, tile, q0, q1);
   }
+  if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, q0, q1);
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    const int64_t next = tile + gridDim.x;
-    if (next < ntiles) load_tile(next, q0, q1);
+    const int64_t next = tile + gridDim.x, next2 = next + gridDim.x;
+    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
+    if (next2 < ntiles) load_tile(next2, q0, q1);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -226,10 +232,9 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (gr < n) dst[((second && row_map) ? (int64_t)row_map[gr] : gr) * ldd] = acc[r] + add;
+        if (gr < n) dst[((second && row_map) ? (int64_t)rmap[buf][(r & 3) + 8 * (r >> 2) + 4 * fh] : gr) * ldd] = acc[r] + add;
       }
     }
-    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
     __syncthreads();
     buf ^= 1;
   }
@@ -261,20 +266,32 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
                                                      float* __restrict__ x_copy, int64_t ld_copy,
                                                      const float* __restrict__ W2, int H2, int64_t ldw2,
                                                      const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
-                                                     const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BS_ROWS][B3_LD];
+                                                     const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves,
+                                                     int nsl1, int y2_vec) {
+  // LDS: A planes [2][3][32][B3_LD] bf16 | C staging [2][32][ldc] float | row map [2][32] int
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __bf16 (*APlanes)[3][BS_ROWS][B3_LD];
+  APlanes As = reinterpret_cast<APlanes>(smem);
+  const int ldc = nslab_waves * 32 + 4;
+  float* Cs = reinterpret_cast<float*>(smem + sizeof(__bf16) * 2 * 3 * BS_ROWS * B3_LD);
+  int* rmap = reinterpret_cast<int*>(Cs + 2 * BS_ROWS * ldc);
+
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int N = S + H2;
+  // slabs 0 .. nsl1-1 cover the S projection columns, the following slabs the H2 columns of the second block
+  // (each block starts on a slab boundary so that both are 16-byte aligned in the C staging tile)
   const int slab = blockIdx.y * nslab_waves + wv;
-  const bool slab_active = wv < nslab_waves && slab * 32 < N;
-  const int c = slab_active ? slab * 32 + fr : N;
+  const int nsl2 = (H2 + 31) >> 5;
+  const bool slab_active = wv < nslab_waves && slab < nsl1 + nsl2;
+  const bool second = slab >= nsl1;
+  const int c = second ? (slab - nsl1) * 32 + fr : slab * 32 + fr;       // column inside its block
+  const bool col_ok = slab_active && (second ? c < H2 : c < S);
 
   // weight slab as MFMA B operands: lane (fr, fh), k-step s holds W[c][16 s + 8 fh + j], j = 0..7, in three planes
   bf16x8 bw[3][KS];
   {
-    const float* wrow = c < S ? V + (int64_t)c * ldv : (c < N ? W2 + (int64_t)(c - S) * ldw2 : nullptr);
+    const float* wrow = col_ok ? (second ? W2 + (int64_t)c * ldw2 : V + (int64_t)c * ldv) : nullptr;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -288,12 +305,9 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
         bw[2][s][j] = h3;
       }
   }
-  const bool second = c >= S;
-  float* dst = c < N ? (second ? Y2 + (c - S) : Xp + c) : nullptr;
-  const int64_t ldd = second ? ldy2 : ldp;
-  const float add = (second && b2 && c < N) ? b2[c - S] : 0.f;
+  const float add = (col_ok && second && b2) ? b2[c] : 0.f;
 
-  for (int i = threadIdx.x; i < 2 * 3 * BS_ROWS * B3_LD / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(&As[0][0][0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < 2 * 3 * BS_ROWS * B3_LD / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
   __syncthreads();
 
   const int d4 = d >> 2;
@@ -315,6 +329,8 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
   };
   auto store_tile = [&](int buf, int64_t tile, const float4& q0, const float4& q1) {
     const int64_t row0 = tile * BS_ROWS;
+    if (threadIdx.x < BS_ROWS)
+      rmap[buf * BS_ROWS + threadIdx.x] = (row_map && row0 + threadIdx.x < n) ? row_map[row0 + threadIdx.x] : (int)(row0 + threadIdx.x);
     const int idx[2] = {(int)threadIdx.x, (int)(threadIdx.x + blockDim.x)};
     const float4 q[2] = {q0, q1};
 #pragma unroll
@@ -339,18 +355,53 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
       }
     }
   };
+  // C staging tile -> global memory as whole rows: 16-byte stores, every row of Xp / Y2 is one contiguous run
+  const int g1 = min(nsl1 - (int)blockIdx.y * nslab_waves, nslab_waves);   // slabs of this column group in block 1
+  const int w1 = max(g1, 0) * 8;                                           // float4 per staged row, first block
+  const int w2 = (nslab_waves - max(g1, 0)) * 8;                           // float4 per staged row, second block
+  const int col1 = blockIdx.y * nslab_waves * 32;                          // first Xp column of this group
+  const int col2 = max((int)blockIdx.y * nslab_waves - nsl1, 0) * 32;      // first Y2 column of this group
+  auto write_out = [&](int cb, int64_t tile) {
+    const int64_t row0 = tile * BS_ROWS;
+    const float* cs = Cs + cb * BS_ROWS * ldc;
+    for (int i = threadIdx.x; i < BS_ROWS * w1; i += blockDim.x) {
+      const int r = i / w1, c4 = i - r * w1;
+      if (row0 + r < n && col1 + 4 * c4 < ldp)   // Xp rows are padded to ldp >= 32 ceil(S/32): whole float4 always fit
+        *reinterpret_cast<float4*>(Xp + (row0 + r) * ldp + col1 + 4 * c4) = *reinterpret_cast<const float4*>(cs + r * ldc + 4 * c4);
+    }
+    for (int i = threadIdx.x; i < BS_ROWS * w2; i += blockDim.x) {
+      const int r = i / w2, c4 = i - r * w2;
+      if (row0 + r >= n) continue;
+      const int cc = col2 + 4 * c4;
+      const float4 v = *reinterpret_cast<const float4*>(cs + r * ldc + max(g1, 0) * 32 + 4 * c4);
+      float* yrow = Y2 + (int64_t)rmap[cb * BS_ROWS + r] * ldy2;
+      if (y2_vec && cc + 3 < H2) {
+        *reinterpret_cast<float4*>(yrow + cc) = v;
+      } else {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cc + j < H2) yrow[cc + j] = e[j];
+      }
+    }
+  };
 
+  // software pipeline, two tiles deep: registers hold tile t+1 (loaded during iteration t-1) and go to LDS at the top
+  // of iteration t; the HBM loads of tile t+2 are issued right after and have the whole iteration to land.  The C
+  // tile is double buffered too, so one barrier per tile orders everything.
   int64_t tile = blockIdx.x;
   float4 q0, q1;
   if (tile < ntiles) {
     load_tile(tile, q0, q1);
     store_tile(0, tile, q0, q1);
   }
+  if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, q0, q1);
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    const int64_t next = tile + gridDim.x;
-    if (next < ntiles) load_tile(next, q0, q1);
+    const int64_t next = tile + gridDim.x, next2 = next + gridDim.x;
+    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
+    if (next2 < ntiles) load_tile(next2, q0, q1);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -367,20 +418,19 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
       }
-    }
-    if (dst) {
-      const int64_t row0 = tile * BS_ROWS;
+      float* cs = Cs + buf * BS_ROWS * ldc + wv * 32 + fr;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (gr < n) dst[((second && row_map) ? (int64_t)row_map[gr] : gr) * ldd] = acc[r] + add;
-      }
+      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
     }
-    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
     __syncthreads();
+    write_out(buf, tile);
     buf ^= 1;
   }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
+}
+
+static size_t bf3_lds_bytes(int nwaves) {
+  return sizeof(__bf16) * 2 * 3 * BS_ROWS * B3_LD + sizeof(float) * 2 * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
 }
 
 }  // namespace fsw
@@ -398,31 +448,43 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
   const bool vec = (ldx % 4 == 0) && (ldv % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                    (H2 == 0 || ((ldw2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0)));
   if (vec && d % 4 == 0 && d <= 128) {
-    // B-stationary kernel: one wave per 32-column slab (<= 16 waves per workgroup), persistent over 32-row tiles
-    // (<= 12 slab waves so that the 64 B-operand registers fit without spilling; >= 8 waves so that every X tile
-    //  is two 16-byte loads per thread -- waves without a slab only help moving X)
-    const int nslabs = (int)ceil_div(S + H2, 32);
+    // B-stationary kernels: one wave per 32-column slab, persistent over 32-row tiles (<= 12 slab waves so that the
+    // B-operand registers fit without spilling; >= 8 waves so that every X tile is two 16-byte loads per thread --
+    // waves without a slab only help moving X)
+    const bool exact = getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
+    const int nsl1 = (int)ceil_div(S, 32), nsl2 = (int)ceil_div(H2, 32);
+    const int nslabs = exact ? (int)ceil_div(S + H2, 32) : nsl1 + nsl2;
     const int ngroups = (int)ceil_div(nslabs, 12);
     const int nwaves = (int)ceil_div(nslabs, ngroups);
     const int64_t ntiles = ceil_div(n, BS_ROWS);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, 256), (unsigned)ngroups);
     const int threads = std::max(nwaves, 8) * 64;
-    // FSW_PROJECT_EXACT_FP32=1 selects the exact-fp32 MFMA kernel instead of the bf16x3 one (same accuracy class,
-    // 2.7x fewer matrix-core cycles); read once
-    static const bool exact = getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
-#define FSW_LAUNCH_BS(KERNEL, T)                                                                                          \
-  KERNEL<T><<<grid, threads, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, b2, Y2, \
-                                          ldy2, row_map, ntiles, nwaves)
     if (exact) {
-      if (d <= 32) FSW_LAUNCH_BS(k_project_bs, 16);
-      else if (d <= 64) FSW_LAUNCH_BS(k_project_bs, 32);
-      else FSW_LAUNCH_BS(k_project_bs, 64);
-    } else {
-      if (d <= 32) FSW_LAUNCH_BS(k_project_bf3, 2);
-      else if (d <= 64) FSW_LAUNCH_BS(k_project_bf3, 4);
-      else FSW_LAUNCH_BS(k_project_bf3, 8);
-    }
+      // FSW_PROJECT_EXACT_FP32=1: exact-fp32 MFMA kernel instead of bf16x3 (same accuracy class, 2.7x the matrix cycles)
+#define FSW_LAUNCH_BS(KQ)                                                                                                   \
+  k_project_bs<KQ><<<grid, threads, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, b2, Y2, \
+                                                 ldy2, row_map, ntiles, nwaves)
+      if (d <= 32) FSW_LAUNCH_BS(16);
+      else if (d <= 64) FSW_LAUNCH_BS(32);
+      else FSW_LAUNCH_BS(64);
 #undef FSW_LAUNCH_BS
+    } else {
+      FSW_REQUIRE(ldp >= (int64_t)nsl1 * 32 && ldp % 4 == 0 && (uintptr_t)Xp % 16 == 0,
+                  "fsw_project: Xp must be 16-byte aligned with ldp >= 32*ceil(S/32), ldp %% 4 == 0");
+      const int y2_vec = (H2 > 0 && ldy2 % 4 == 0 && (uintptr_t)Y2 % 16 == 0) ? 1 : 0;
+      const size_t lds = bf3_lds_bytes(nwaves);
+#define FSW_LAUNCH_BF3(KS)                                                                                                  \
+  do {                                                                                                                      \
+    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_project_bf3<KS>),                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
+    k_project_bf3<KS><<<grid, threads, lds, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, \
+                                                      b2, Y2, ldy2, row_map, ntiles, nwaves, nsl1, y2_vec);                 \
+  } while (0)
+      if (d <= 32) FSW_LAUNCH_BF3(2);
+      else if (d <= 64) FSW_LAUNCH_BF3(4);
+      else FSW_LAUNCH_BF3(8);
+#undef FSW_LAUNCH_BF3
+    }
     FSW_LAUNCH_CHECK();
     return 0;
   }
