@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--edges", type=int, default=N_EDGES)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-slices", type=int, default=64)
+    ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
     return ap.parse_args()

@@ -54,7 +54,8 @@ def sharded_embed_into(emb_mod, X, graph, out, out_scale=1.0, group=None, x_copy
     parts = slice_partition(emb_mod.nSlices, world)
     wmax = max(b - a for a, b in parts)
     ka, kb = parts[rank]
-    local = torch.zeros((graph.num_rows, has_mass + wmax), dtype=X.dtype, device=X.device)
+    # columns past this rank's block (only when S is not divisible by the world size) are never read back
+    local = torch.empty((graph.num_rows, has_mass + wmax), dtype=X.dtype, device=X.device)
     if kb > ka:
         emb_mod.embed_into(X, graph, local, out_scale=out_scale, slice_range=(ka, kb), x_copy=x_copy)
     elif x_copy is not None:
