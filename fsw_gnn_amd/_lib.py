@@ -51,6 +51,8 @@ _SIGNATURES = {
                                               c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, c_vp, c_i64,
                                           ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
+    "fsw_unit_dcoeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
+    "fsw_embed_backward_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_segcumsum_workspace_bytes": (c_sz, [c_i64]),
     "fsw_segcumsum": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_sz, c_vp]),
     # legacy ABI, exact reference signatures (reference fsw_embedding.py:2952-2977)

@@ -1,0 +1,179 @@
+// Backward of the fused neighbourhood kernel, register path, unit weights.  gfx950.
+//
+// The reference differentiates its chain of sparse ops by reverse-mode autograd (ag.*.backward, reference
+// fsw_embedding.py:1284-2257): sum_sparseToDense.backward expands the output gradient to E*S entries,
+// sinc_cos_sparse.backward multiplies saved E*S factors (:1796-1817), cumsum_sparse.backward is a reverse segmented
+// cumsum (:2158-2172), permute_sparse.backward re-sorts E*S int64 keys (:1284-1325) and sort.backward scatters
+// (:2055-2070).  With unit weights the forward is  out[i,k] = sum_t C[D_i][t][k] p_(t)  with a coefficient table that
+// depends on (degree, rank, slice) only, so for an output gradient g:
+//     d L / d Xp[j,k]  = sum over edges j->i of  g[i,k] C[D_i][rank_ik(j)][k]
+//     d L / d xi_k     = sum_i g[i,k] sum_t dC[D_i][t][k] p_(t),        dC = d C / d xi  (second float64 table)
+// One wavefront = one recipient row x one 64-slice chunk, lane = slice, as in the forward.  Ranks come from
+// D(D-1)/2 register compares (no second sort: rank[u] += p_t < p_u, rank[t] += otherwise), the two coefficient
+// rows of the wave's chunk sit in LDS indexed by the lane's rank, and every neighbour receives ONE wave-wide
+// no-return global_atomic_add_f32 on 256 contiguous bytes of gXp[col_t] -- the full-rate shape for float atomics
+// on this part (atomics execute at the memory side, ~1.3 TB/s of added bytes chip-wide; this kernel is bound by that).
+// gX = gXp . V and gV = gXp^T . X are two plain GEMMs left to the BLAS.
+#include "fsw_common.h"
+
+namespace fsw {
+
+constexpr int kBwdRows = 32;
+constexpr double kPiB = 3.14159265358979323846;
+
+// d/dxi [ (1 + xi) Delta_t ] for weights 1/D:  Delta = 2 w sinc(xi w) cos(B),  B = pi xi (2c - w)
+__global__ void __launch_bounds__(256) k_unit_dtable(const float* __restrict__ freqs, int S, int max_deg,
+                                                     float* __restrict__ dtable, int64_t ldt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y;
+  int D = 1;
+  while ((D + 1) * D / 2 <= row) ++D;
+  const int t = row - D * (D - 1) / 2;
+  if (k >= S || D > max_deg) return;
+  const double xi = (double)freqs[k];
+  const double w = 1.0 / D, c = (double)(t + 1) / D;
+  const double z = xi * w;
+  const double sinc = (z == 0.0) ? 1.0 : sinpi(z) / (kPiB * z);
+  const double dsinc = (z == 0.0) ? 0.0 : (cospi(z) - sinc) / z;
+  const double B = xi * (2.0 * c - w);  // in units of pi
+  const double delta = 2.0 * w * sinc * cospi(B);
+  const double ddelta = 2.0 * w * (w * dsinc * cospi(B) - sinc * kPiB * (2.0 * c - w) * sinpi(B));
+  dtable[(int64_t)row * ldt + k] = (float)(delta + (1.0 + xi) * ddelta);
+}
+
+template <int D>
+__device__ __forceinline__ void unit_bwd_rows(int p, int pe, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                              const int32_t* __restrict__ perm, const float* __restrict__ Xp, int64_t ldp,
+                                              const float* __restrict__ table, const float* __restrict__ dtable, int64_t ldt,
+                                              const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
+                                              float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
+                                              float* __restrict__ cS /* [2][D][64] wave-private LDS */, int k, int kc, bool kvalid) {
+  const int lane = lane_id();
+  const int64_t trow = (int64_t)(D * (D - 1) / 2);
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    cS[t * kWave + lane] = out_scale * table[(trow + t) * ldt + kc];
+    cS[(D + t) * kWave + lane] = out_scale * dtable[(trow + t) * ldt + kc];
+  }
+  __builtin_amdgcn_wave_barrier();
+  float gf = 0.f;
+  for (; p < pe; ++p) {
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const float gi = kvalid ? g[(int64_t)node * ldg + gcol0 + k] : 0.f;
+    float key[D];
+    int cidx[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+      cidx[t] = col[start + t];
+      key[t] = Xp[(int64_t)cidx[t] * ldp + kc];
+    }
+    int rank[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) rank[t] = 0;
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+      for (int t = u + 1; t < D; ++t) {
+        const int before = key[t] < key[u];   // t sorts ahead of u only when strictly smaller (ties keep edge order)
+        rank[u] += before;
+        rank[t] += 1 - before;
+      }
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+      const float c = cS[rank[t] * kWave + lane];
+      const float dc = cS[(D + rank[t]) * kWave + lane];
+      gf = fmaf(gi * dc, key[t], gf);
+      if (kvalid) atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * c);
+    }
+  }
+  if (kvalid && gfreq) atomicAdd(gfreq + k, gf);
+}
+
+#define FSW_BWD_CASES(X)                                                                                               \
+  X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
+  X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
+template <int DLO, int DHI>
+__global__ void __launch_bounds__(256) k_embed_reg_unit_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
+                                                            const float* __restrict__ Xp, int64_t ldp, int S,
+                                                            const float* __restrict__ table, const float* __restrict__ dtable,
+                                                            int64_t ldt, const float* __restrict__ g, int64_t ldg, int gcol0,
+                                                            float out_scale, float* __restrict__ gXp, int64_t ldgp,
+                                                            float* __restrict__ gfreq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wv = wave_id();
+  const int chunk = blockIdx.y * 4 + wv;
+  if (chunk * kWave >= S) return;
+  const int k = chunk * kWave + lane_id();
+  const bool kvalid = k < S;
+  const int kc = kvalid ? k : S - 1;
+  int D, p = 0, pe = 0;
+  {
+    int b = blockIdx.x;
+    for (D = DHI; D >= DLO; --D) {
+      const int lo = bin_start[D], hi = bin_start[D + 1];
+      const int nb = (hi - lo + kBwdRows - 1) / kBwdRows;
+      if (b < nb) {
+        p = lo + b * kBwdRows;
+        pe = min(p + kBwdRows, hi);
+        break;
+      }
+      b -= nb;
+    }
+    if (D < DLO) return;
+  }
+  float* cS = smem + wv * (2 * DHI * kWave);
+  switch (D) {
+#define X(d)                                                                                                          \
+  case d:                                                                                                             \
+    if constexpr (d >= DLO && d <= DHI)                                                                               \
+      unit_bwd_rows<d>(p, pe, rowptr, col, perm, Xp, ldp, table, dtable, ldt, g, ldg, gcol0, out_scale, gXp, ldgp,    \
+                       gfreq, cS, k, kc, kvalid);                                                                     \
+    break;
+    FSW_BWD_CASES(X)
+#undef X
+    default:
+      break;
+  }
+}
+
+}  // namespace fsw
+
+using namespace fsw;
+
+extern "C" int fsw_unit_dcoeff_table(const float* freqs, int S, int max_deg, float* dtable, int64_t ldt, fsw_stream_t stream) {
+  FSW_REQUIRE(freqs && dtable, "fsw_unit_dcoeff_table: null pointer");
+  FSW_REQUIRE(S >= 1 && ldt >= S && max_deg >= 1 && max_deg <= FSW_REG_MAX_DEG,
+              "fsw_unit_dcoeff_table: need S >= 1, ldt >= S, 1 <= max_deg <= %d", FSW_REG_MAX_DEG);
+  dim3 grid((unsigned)ceil_div(S, 256), (unsigned)(max_deg * (max_deg + 1) / 2));
+  k_unit_dtable<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(freqs, S, max_deg, dtable, ldt);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
+                                      int64_t ldgp, float* gfreq, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  FSW_REQUIRE(args && dtable && g && gXp, "fsw_embed_backward_f32: null pointer");
+  const fsw_embed_args& a = *args;
+  FSW_REQUIRE(a.rowptr && a.col && a.perm && a.bin_start && a.Xp && a.unit_table, "fsw_embed_backward_f32: null pointer in args");
+  FSW_REQUIRE(a.w == nullptr && a.tau <= 1.f, "fsw_embed_backward_f32: unit weights with tau <= 1 only (this round)");
+  FSW_REQUIRE(a.num_lds_rows == 0 && a.num_global_rows == 0,
+              "fsw_embed_backward_f32: rows with in-degree > %d are not supported by the backward yet", FSW_REG_MAX_DEG);
+  FSW_REQUIRE(a.S >= 1 && a.ldp >= a.S && a.ldt >= a.S && ldgp >= a.S && ldg >= a.S + a.has_mass, "fsw_embed_backward_f32: bad sizes");
+  if (a.num_reg_rows == 0) return 0;
+  const int64_t rows = a.num_reg_rows < 0 ? a.num_rows : a.num_reg_rows;
+  dim3 grid((unsigned)(ceil_div(rows, kBwdRows) + FSW_REG_MAX_DEG), (unsigned)ceil_div(a.S, 4 * kWave));
+  // long rows first; the two launches differ in the LDS they need for the wave-private coefficient rows
+  k_embed_reg_unit_bwd<17, 32><<<grid, 256, 4 * 2 * 32 * kWave * sizeof(float), stream>>>(
+      a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale, gXp,
+      ldgp, gfreq);
+  FSW_LAUNCH_CHECK();
+  k_embed_reg_unit_bwd<1, 16><<<grid, 256, 4 * 2 * 16 * kWave * sizeof(float), stream>>>(
+      a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale, gXp,
+      ldgp, gfreq);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}

@@ -184,15 +184,22 @@ class FSW_conv(_Base):
         assert edge_features is None, 'Edge features should not be provided since edgefeat_dim = 0'
         if vertex_features.device.type != 'cuda':
             raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
-        if torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in emb_mod.parameters())):
-            raise NotImplementedError("fsw_gnn_amd: the backward pass of the embedding is not implemented yet "
-                                      "(SURVEY.md 8f #1); call forward under torch.no_grad()")
+        needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters()))
         n = vertex_features.size(0)
         x = vertex_features.contiguous()
         graph = self.build_graph(edge_index, n)
         E = self.embed_dim
         scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
         sharded = getattr(self, '_slice_parallel', False)
+
+        if needs_grad:
+            # training path: differentiable embedding (HIP forward + backward kernels), the tail through torch autograd
+            if sharded:
+                raise NotImplementedError("fsw_gnn_amd: slice-parallel training is not implemented")
+            emb = emb_mod.embed_autograd(x, graph)
+            h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
+            out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
+            return self.bn_final(out) if self.bn_final is not None else out
 
         prepared = None
         if self._fusable() and not sharded:

@@ -8,8 +8,10 @@ The computation is NOT the reference's chain of torch.sparse_coo operations: for
 sort + cumulative-sum + Fourier readout kernels (fsw_embed_f32).  There is no CPU or pure-PyTorch fallback:
 tensors must live on a HIP device and the native library must be present.
 
+Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kernel, csrc/embed_bwd.hip) for unit
+weights, tau <= 1 and in-degrees <= 32 -- FSW_conv's default configuration; other configurations raise.
 Not implemented in this round (raise NotImplementedError): d_edge > 0 (edge features), Cartesian mode
-(nSlices x nFreqs), autograd backward, mutual-coherence minimisation at initialisation (the flag is accepted,
+(nSlices x nFreqs), gradients w.r.t. W, mutual-coherence minimisation at initialisation (the flag is accepted,
 slices stay random unit vectors).
 """
 import ctypes
@@ -33,6 +35,68 @@ _MASS_FN = {"identity": 0, "sqrt": 1, "log": 2}
 
 def _round_up(v, m):
     return (v + m - 1) // m * m
+
+
+class _EmbedGraphFn(torch.autograd.Function):
+    """out = out_scale * E(X, graph) with gradients for X, projVecs, freqs, bias and the total-mass scale.
+
+    Forward runs the same HIP kernels as inference (prepare + embed_into); backward runs csrc/embed_bwd.hip
+    (neighbourhood ranks recomputed in registers, one wave-wide float atomic per neighbour into gXp) and two plain
+    GEMMs.  Replaces the reference's chain of sparse autograd Functions (fsw_embedding.py:1232-2257).
+    Supported this round: unit weights, tau <= 1, total_mass_encoding_method 'plain', in-degrees <= 32.
+    """
+
+    @staticmethod
+    def forward(ctx, X, projVecs, freqs, bias, mass_scale, module, graph, out_scale):
+        with torch.no_grad():
+            prepared = module.prepare(X, graph)
+            st = prepared["stats"]
+            if not prepared["unit_fast"]:
+                raise NotImplementedError("fsw_gnn_amd: backward needs unit edge weights and total_mass_pad_thresh <= 1")
+            if st[_lib.STAT_NUM_LDS] or st[_lib.STAT_NUM_GLOBAL]:
+                raise NotImplementedError("fsw_gnn_amd: backward does not support in-degrees > %d yet" % _lib.REG_MAX_DEG)
+            if module.encode_total_mass and module.total_mass_encoding_method != 'plain':
+                raise NotImplementedError("fsw_gnn_amd: backward supports total_mass_encoding_method='plain' only")
+            out = torch.empty((graph.num_rows, module.d_out), dtype=X.dtype, device=X.device)
+            module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
+        ctx.module, ctx.graph, ctx.prepared, ctx.out_scale = module, graph, prepared, float(out_scale)
+        ctx.save_for_backward(X, projVecs, freqs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        module, graph, prepared, out_scale = ctx.module, ctx.graph, ctx.prepared, ctx.out_scale
+        X, V, freqs = ctx.saved_tensors
+        L = _lib.lib()
+        S, has_mass = module.nSlices, (1 if module.encode_total_mass else 0)
+        g = g.contiguous()
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        ldp, Xp, table, st = prepared["ldp"], prepared["Xp"], prepared["table"], prepared["stats"]
+        gX = gV = gfreqs = gbias = gscale = None
+        need_xp = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if need_xp or ctx.needs_input_grad[2]:
+            gXp = torch.zeros((X.shape[0], ldp), dtype=torch.float32, device=X.device)
+            dtable = torch.empty_like(table)
+            fr = freqs.detach()
+            _lib.check(L.fsw_unit_dcoeff_table(_lib.ptr(fr), S, _lib.REG_MAX_DEG, _lib.ptr(dtable), ldp, stream), "fsw_unit_dcoeff_table")
+            gf = torch.zeros(S, dtype=torch.float32, device=X.device)
+            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass)
+            _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
+                                                _lib.ptr(gf), stream), "fsw_embed_backward_f32")
+            if ctx.needs_input_grad[0]:
+                gX = gXp[:, :S] @ V.detach()
+            if ctx.needs_input_grad[1]:
+                gV = gXp[:, :S].t() @ X.detach()
+            if ctx.needs_input_grad[2]:
+                gfreqs = gf
+        if ctx.needs_input_grad[3]:
+            gbias = out_scale * g[:, :module.d_out].sum(dim=0)
+        if ctx.needs_input_grad[4]:
+            m = graph.in_degrees()                                         # unit weights: total mass = in-degree
+            fn = module.total_mass_encoding_function
+            fm = m if fn == 'identity' else (2 * (m / (torch.sqrt(m + 1) + 1)) if fn == 'sqrt' else torch.log1p(m))
+            gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())
+        return gX, gV, gfreqs, gbias, gscale, None, None, None
 
 
 class FSW_embedding(nn.Module):
@@ -239,10 +303,9 @@ class FSW_embedding(nn.Module):
         assert X.device == self.get_device(), ("X is on the wrong device. Expected %s, got %s" % (self.get_device(), X.device))
         if X.device.type != 'cuda':
             raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
-        if torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters())
-                                        or (torch.is_tensor(W) and W.requires_grad)):
-            raise NotImplementedError("fsw_gnn_amd: the backward pass is not implemented yet (SURVEY.md 8f #1); "
-                                      "call forward under torch.no_grad()")
+        needs_grad = torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if torch.is_grad_enabled() and torch.is_tensor(W) and W.requires_grad:
+            raise NotImplementedError("fsw_gnn_amd: gradients with respect to the weights W are not implemented")
         if torch.is_tensor(W):
             assert W.dtype == self.get_dtype(), ("W has the wrong dtype. Expected %s, got %s" % (self.get_dtype(), W.dtype))
             assert W.device == self.get_device(), ("W is on the wrong device. Expected %s, got %s" % (self.get_device(), W.device))
@@ -295,9 +358,18 @@ class FSW_embedding(nn.Module):
             num_rows, out_shape = B * nR, batch_dims + (nR,)
 
         graph = build_csr(rec, snd, wvals, num_rows, Xf.shape[0])
-        out = torch.empty((num_rows, self.d_out), dtype=X.dtype, device=X.device)
-        self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
+        if needs_grad:
+            out = self.embed_autograd(Xf.contiguous(), graph)
+        else:
+            out = torch.empty((num_rows, self.d_out), dtype=X.dtype, device=X.device)
+            self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
         return out.reshape(out_shape + (self.d_out,))
+
+    def embed_autograd(self, X, graph, out_scale=1.0):
+        """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn."""
+        bias = self.bias if self.enable_bias else None
+        scale = self.total_mass_encoding_scale if self.encode_total_mass else None
+        return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, self, graph, out_scale)
 
     # ------------------------------------------------------------------------------------------------
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):

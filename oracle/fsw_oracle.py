@@ -228,3 +228,93 @@ def segcumsum(values, segment_ids):
     for a, b in zip(bounds[:-1], bounds[1:]):
         out[a:b] = np.cumsum(values[a:b])
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# backward of the embedding core                      fsw_embedding.py:1232-2257 (the ag.*.backward chain)
+# --------------------------------------------------------------------------------------------------
+def _dsinc(z):
+    """d/dz sinc(z), sinc(z) = sin(pi z)/(pi z)  (reference sp.dsinc, fsw_embedding.py:2760-2774)."""
+    z = np.asarray(z, dtype=np.float64)
+    safe = np.where(z == 0, 1.0, z)
+    return np.where(z == 0, 0.0, (np.cos(np.pi * z) - np.sinc(z)) / safe)
+
+
+def fsw_embed_csr_backward(X, rowptr, col, w, projVecs, freqs, G, total_mass_pad_thresh=1.0, chunk_elems=1 << 22,
+                           return_gXp=False, Xp_override=None):
+    """Gradients of sum(out * G) for out = fsw_embed_csr(...) with respect to X, projVecs and freqs (float64).
+
+    The reference obtains them by reverse-mode autograd through its sparse ops: sum_sparseToDense.backward,
+    mul/sinc_cos backward (fsw_embedding.py:1796-1817), cumsum_sparse.backward = reverse segcumsum (:2158-2172),
+    permute_sparse.backward (:1284-1325), sort.backward = scatter (:2055-2070), tensordot.  With the sort order
+    held fixed (it is piecewise constant) this is
+        d out[r,k] / d p_(t)  = (1 + xi_k) Delta_t
+        d out[r,k] / d xi_k   = sum_t Delta_t p_(t) + (1 + xi_k) sum_t (d Delta_t / d xi) p_(t)
+        d Delta / d xi        = 2 w [ w sinc'(xi w) cos(B) - sinc(xi w) pi (2c - w) sin(B) ],  B = pi xi (2c - w)
+    followed by gX = gXp . V, gV = gXp^T . X.  The weights are treated as constants.
+    Xp_override: use these projections (e.g. the float32 ones of the path under test) to decide the sort order;
+    two neighbours whose projections agree to float32 rounding may otherwise swap ranks between float32 and
+    float64, which moves g (C[s] - C[s+1]) between two entries of gXp (the gradient is discontinuous there).
+    """
+    X = np.asarray(X, dtype=np.float64)
+    V = np.asarray(projVecs, dtype=np.float64)
+    xi = np.asarray(freqs, dtype=np.float64)
+    G = np.asarray(G, dtype=np.float64)
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    w = np.asarray(w, dtype=np.float64)
+    tau = float(total_mass_pad_thresh)
+    nrows = rowptr.shape[0] - 1
+    S = V.shape[0]
+    deg = np.diff(rowptr)
+    mass = np.zeros(nrows)
+    np.add.at(mass, np.repeat(np.arange(nrows), deg), w)
+    deficit = np.maximum(tau - mass, 0)
+    any_deficit = bool((deficit > 0).any())
+    denom = np.maximum(mass, tau) if any_deficit else mass
+    Xp = X @ V.T if Xp_override is None else np.asarray(Xp_override, dtype=np.float64)
+    gXp = np.zeros_like(Xp)
+    gxi = np.zeros(S)
+    for D in np.unique(deg):
+        rows = np.nonzero(deg == D)[0]
+        Dp = int(D) + (1 if any_deficit else 0)
+        if D == 0:
+            continue
+        step = max(1, chunk_elems // max(1, Dp * S))
+        for a in range(0, rows.shape[0], step):
+            rr = rows[a:a + step]
+            R = rr.shape[0]
+            idx = rowptr[rr][:, None] + np.arange(D)[None, :]
+            keys = np.zeros((R, Dp, S))
+            wts = np.zeros((R, Dp))
+            keys[:, :D, :] = Xp[col[idx]]
+            wts[:, :D] = w[idx]
+            if any_deficit:
+                wts[:, D] = deficit[rr]
+            wts = wts / denom[rr][:, None]
+            order = np.argsort(keys, axis=1, kind="stable")
+            ks = np.take_along_axis(keys, order, axis=1)
+            ws = np.take_along_axis(np.broadcast_to(wts[:, :, None], keys.shape), order, axis=1)
+            c = np.cumsum(ws, axis=1)
+            x3 = xi[None, None, :]
+            B = np.pi * x3 * (2 * c - ws)
+            sc = np.sinc(x3 * ws)
+            delta = 2 * ws * sc * np.cos(B)
+            ddelta = 2 * ws * (ws * _dsinc(x3 * ws) * np.cos(B) - sc * np.pi * (2 * c - ws) * np.sin(B))
+            g = G[rr][:, None, :]                                              # [R, 1, S]
+            gxi += np.sum(g * (delta * ks + (1 + x3) * ddelta * ks), axis=(0, 1))
+            gk_sorted = g * (1 + x3) * delta                                   # gradient w.r.t. the sorted keys
+            gk = np.zeros_like(gk_sorted)
+            np.put_along_axis(gk, order, gk_sorted, axis=1)                    # back to neighbour order
+            np.add.at(gXp, col[idx], gk[:, :D, :])                             # the pad element has no source row
+    if return_gXp:
+        return gXp @ V, gXp.T @ X, gxi, gXp
+    return gXp @ V, gXp.T @ X, gxi
+
+
+def mass_value(mass, function="identity"):
+    if function == "identity":
+        return mass
+    if function == "sqrt":
+        return 2 * (mass / (np.sqrt(mass + 1) + 1))
+    return np.log1p(mass)

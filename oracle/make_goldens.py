@@ -191,6 +191,49 @@ def case_segcumsum(emb):
     save("segcumsum", **arrays)
 
 
+def case_grads(emb, conv):
+    """Backward goldens: d(sum(out * R))/d{X, projVecs, freqs, bias, mass scale} in float64 from the
+    reference's own autograd Functions (fsw_embedding.py:1232-2257), tiny graph and the 10k-node conv layer."""
+    g = np.load(os.path.join(GOLD, "tiny_graph.npz"))
+    dt = torch.float64
+    n, d, S = 64, 8, 16
+    X0, V, fr, bias, ei = g["X"], g["V"], g["freqs"].copy(), g["bias"], g["edge_index"]
+    fr[0] = 0.37                                 # keep xi > 0 here: d/dxi at xi = 0 is covered by the oracle only
+    R = synth.normal(91, 1, (n, S + 1), dtype=np.float64)
+    arrays = {"R": R, "freqs": fr}
+    adj, _, _ = conv.FSW_conv.edge_index_to_adj(torch.from_numpy(ei), None, n, 0, dt)
+    wv = g["adj3_values"]
+    adj3 = torch.sparse_coo_tensor(adj.indices(), torch.from_numpy(wv), adj.shape).coalesce()
+    for tag, A in (("unit", adj), ("weighted", adj3)):
+        Em = emb.FSW_embedding(d_in=d, d_out=S + 1, encode_total_mass=True, total_mass_encoding_scale=0.7, learnable_slices=True,
+                               learnable_freqs=True, learnable_total_mass_encoding_scale=True, device="cpu", dtype=dt,
+                               load_custom_cuda_lib=False)
+        set_params(Em, V, fr, bias=bias, scale=0.7)
+        X = T(X0, dt).requires_grad_(True)
+        out = Em(X, A, graph_mode=True)
+        (out * torch.from_numpy(R)).sum().backward()
+        arrays.update({"out_" + tag: out.detach().numpy(), "gX_" + tag: X.grad.numpy(), "gV_" + tag: Em.projVecs.grad.numpy(),
+                       "gfreqs_" + tag: Em.freqs.grad.numpy(), "gbias_" + tag: Em.bias.grad.numpy(),
+                       "gscale_" + tag: np.array(float(Em.total_mass_encoding_scale.grad))})
+    save("grads_tiny", **arrays)
+
+    c = cases.conv10k()
+    n, d, out_ch, embed_dim = c["n"], c["d"], c["out_ch"], c["embed_dim"]
+    C = conv.FSW_conv(d, out_ch, embed_dim=embed_dim, device="cpu", dtype=dt)
+    set_params(C.fsw_embed, c["V"], c["freqs"])
+    with torch.no_grad():
+        C.mlp[0].weight.copy_(T(c["lin_w"], dt))
+        C.mlp[0].bias.copy_(T(c["lin_b"], dt))
+    X = T(c["X"], dt).requires_grad_(True)
+    Rc = synth.normal(92, 1, (n, out_ch), dtype=np.float64)
+    y = C(X, torch.from_numpy(c["edge_index"]))
+    (y * torch.from_numpy(Rc)).sum().backward()
+    rows = np.unique(synth.randint(93, 1, n, 256))
+    save("grads_conv10k", rows=rows, gX_rows=X.grad.numpy()[rows], gX_norm=np.array(float(X.grad.norm())),
+         gV=C.fsw_embed.projVecs.grad.numpy(), gfreqs=C.fsw_embed.freqs.grad.numpy(), gW=C.mlp[0].weight.grad.numpy(),
+         gb=C.mlp[0].bias.grad.numpy())
+
+
 def case_er1m(emb, conv, nslices=256, serialize=4):
     # BASELINE config 3: ER-style multigraph 1M nodes / 10M edges, 128 feat, 256 slices (+ degree column)
     t0 = time.time()
@@ -234,10 +277,12 @@ def main():
         case_segcumsum(emb)
         timings.update(case_conv10k(emb, conv))
         case_rmat(emb, conv)
+    elif what == "grads":
+        case_grads(emb, conv)
     elif what == "er1m":
         timings.update(case_er1m(emb, conv))
     else:
-        raise SystemExit("usage: python -m oracle.make_goldens [small|er1m]")
+        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|er1m]")
     json.dump(timings, open(timings_path, "w"), indent=1, sort_keys=True)
 
 

@@ -126,3 +126,40 @@ def test_segcumsum_vectors():
         got = O.segcumsum(g["values_" + tag], g["ids"])
         assert relerr(got, g["slow_" + tag]) == 0.0                   # same left-to-right order as segcumsum_slow
         assert relerr(got, g["out_" + tag]) < tol                     # reference log-step scan, different rounding
+
+
+@pytest.mark.parametrize("tag,which", [("unit", "adj"), ("weighted", "adj3")])
+def test_backward_oracle_matches_reference_autograd(tag, which):
+    """The analytic gradients of the oracle against the reference's autograd (float64 goldens, tiny graph)."""
+    g = golden("tiny_graph")
+    gg = golden("grads_tiny")
+    rp, cl, vv = _tiny_csr(g, which)
+    R = gg["R"]
+    gX, gV, gxi = O.fsw_embed_csr_backward(g["X"], rp, cl, vv, g["V"], gg["freqs"], R[:, 1:])
+    assert relerr(gX, gg["gX_" + tag]) < 1e-10
+    assert relerr(gV, gg["gV_" + tag]) < 1e-10
+    assert relerr(gxi, gg["gfreqs_" + tag]) < 1e-10
+    assert relerr(R.sum(axis=0), gg["gbias_" + tag]) < 1e-12
+    mass = np.zeros(64)
+    np.add.at(mass, np.repeat(np.arange(64), np.diff(rp)), vv)
+    assert abs((R[:, 0] * mass).sum() - float(gg["gscale_" + tag])) < 1e-10 * abs(float(gg["gscale_" + tag]))
+
+
+def test_backward_oracle_conv10k():
+    gg = golden("grads_conv10k")
+    c = cases.conv10k()
+    rowptr, col, w, _ = O.coalesce_edge_index(c["edge_index"], c["n"])
+    X = c["X"].astype(np.float64)
+    emb = O.fsw_embedding_forward(X, rowptr, col, w, c["V"], c["freqs"], encode_total_mass=True)
+    Rc = cases.synth.normal(92, 1, (c["n"], c["out_ch"]), dtype=np.float64)
+    h = np.concatenate([emb, X], axis=1)
+    Wl, bl = c["lin_w"].astype(np.float64), c["lin_b"].astype(np.float64)
+    pre = h @ Wl.T + bl
+    gpre = Rc * np.where(pre >= 0, 1.0, 0.2)                                   # LeakyReLU(0.2) backward
+    gh = gpre @ Wl
+    E = c["embed_dim"]
+    gX_e, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, col, w, c["V"], c["freqs"], gh[:, 1:E])
+    gX = gX_e + gh[:, E:]
+    assert relerr(gX[gg["rows"]], gg["gX_rows"]) < 1e-9
+    assert relerr(gV, gg["gV"]) < 1e-9 and relerr(gxi, gg["gfreqs"]) < 1e-9
+    assert relerr(gpre.T @ h, gg["gW"]) < 1e-9
