@@ -435,3 +435,42 @@ def test_backward_conv10k_training_step(dev):
     with torch.no_grad():
         y2 = conv(X.detach(), ei)
     assert relerr(y2.cpu().numpy(), y.detach().cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("n,E,d,out_ch,embed_dim,kw", [
+    (500, 4000, 6, 10, None, {}),                                   # default embed_dim = 20 -> 19 slices, d % 4 != 0
+    (1200, 9000, 64, 64, None, {}),                                 # default embed_dim = 128 -> 127 slices (odd)
+    (800, 7000, 20, 40, 97, {"mlp_layers": 2}),                     # two-layer MLP: only the first Linear is fused
+    (700, 5000, 16, 8, 33, {"concat_self": False}),                 # no vertex-feature block
+    (900, 8000, 12, 24, 70, {"encode_vertex_degrees": False, "mlp_activation_final": torch.nn.ReLU()}),
+    (600, 5000, 8, 300, 41, {"vertex_degree_encoding_function": "log", "message_weight_vs_self": 0.5}),   # > 256 outputs
+])
+def test_fused_conv_odd_shapes_match_unfused_and_oracle(dev, n, E, d, out_ch, embed_dim, kw):
+    """The fused Linear kernel, the unfused kernels and the oracle agree on shapes off the aligned fast paths."""
+    from fsw_gnn_amd import FSW_conv
+    ei = cases.synth.er_multigraph(n, E, seed=n)
+    X = cases.synth.features(n, d, seed=n + 1)
+    torch.manual_seed(n)
+    conv = FSW_conv(d, out_ch, embed_dim=embed_dim, device=dev, **kw)
+    Xd, eid = t(X, dev), t(ei, dev, torch.int64)
+    with torch.no_grad():
+        assert conv._fusable()
+        y_f = conv(Xd, eid).cpu().numpy()
+        conv.fuse_linear = False
+        y_u = conv(Xd, eid).cpu().numpy()
+    assert relerr(y_f, y_u) < 3e-6
+    conv.cache_graph = True                                                   # CSR reuse gives the same result
+    with torch.no_grad():
+        y_c1 = conv(Xd, eid)
+        g1 = conv._graph_cache[1]
+        y_c2 = conv(Xd, eid)
+    assert conv._graph_cache[1] is g1 and torch.equal(y_c1, y_c2) and relerr(y_c1.cpu().numpy(), y_u) == 0.0
+    em = conv.fsw_embed
+    rowptr, col, w, _ = O.coalesce_edge_index(ei, n)
+    emb = O.fsw_embedding_forward(X, rowptr, col, w, em.projVecs.detach().cpu().numpy(), em.freqs.detach().cpu().numpy(),
+                                  encode_total_mass=em.encode_total_mass,
+                                  total_mass_encoding_function=em.total_mass_encoding_function)
+    h = torch.from_numpy(np.concatenate([conv.message_weight_vs_self * emb, X.astype(np.float64)], axis=1) if conv.concat_self else emb)
+    with torch.no_grad():
+        ref = conv.mlp.double().cpu()(h).numpy()
+    assert relerr(y_f, ref) < TOL
