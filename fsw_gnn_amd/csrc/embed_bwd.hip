@@ -139,6 +139,118 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit_bwd(const int32_t* __res
   }
 }
 
+// ---- general weights (self loops, 'gcn', explicit W, tau > 1), register path -------------------------------------------
+// (1 + xi) Delta_t = F(c_t) - F(c_t - w_t) with F(xi; c) = (1 + xi) sin(2 pi xi c)/(pi xi) and c_t the cumulative
+// normalised weight up to and including the element: the coefficient of neighbour t needs only its own cumulative
+// weight, which D(D+1)/2 compares give without sorting (cum[u] += w[t] when t sorts ahead of u).  Coefficient and
+// xi-derivative in float64 (the two terms of dF/dxi cancel from O(c/xi) to O(1)).
+__device__ __forceinline__ void F_dF(double xi, double c, double& F, double& dF) {
+  const double x = 2.0 * kPiB * xi * c;
+  if (x < 1e-4) {
+    const double q = 1.0 - x * x * (1.0 / 6.0);
+    F = (1.0 + xi) * 2.0 * c * q;
+    dF = 2.0 * c * q - (1.0 + xi) * 2.0 * c * (2.0 * kPiB * c) * (2.0 * kPiB * c) * xi * (1.0 / 3.0);
+    return;
+  }
+  const double ph = xi * c;
+  double s, co;
+  sincospi(2.0 * (ph - rint(ph)), &s, &co);
+  F = (1.0 + xi) * s / (kPiB * xi);
+  dF = -s / (kPiB * xi * xi) + (1.0 + xi) * 2.0 * c * co / xi;
+}
+
+template <int DEG>
+__device__ __forceinline__ void weighted_bwd_rows(int p, int pe, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                  const float* __restrict__ Xp, int64_t ldp, const float* __restrict__ freqs,
+                                                  float tau, const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
+                                                  float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq, int k, int kc,
+                                                  bool kvalid) {
+  const double xi = (double)freqs[kc];
+  float gf = 0.f;
+  for (; p < pe; ++p) {
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const float gi = kvalid ? out_scale * g[(int64_t)node * ldg + gcol0 + k] : 0.f;
+    float key[DEG + 1], wr[DEG + 1];
+    int cidx[DEG];
+    double m = 0.0;
+#pragma unroll
+    for (int t = 0; t < DEG; ++t) {
+      cidx[t] = col[start + t];
+      key[t] = Xp[(int64_t)cidx[t] * ldp + kc];
+      wr[t] = w ? w[start + t] : 1.f;
+      m += (double)wr[t];
+    }
+    const double taud = (double)tau;
+    const double inv = 1.0 / fmax(m, taud);
+    key[DEG] = 0.f;                               // the reference's pad element (fsw_embedding.py:787-821)
+    wr[DEG] = (float)fmax(taud - m, 0.0);
+    double cum[DEG + 1];
+#pragma unroll
+    for (int t = 0; t <= DEG; ++t) cum[t] = (double)wr[t];
+#pragma unroll
+    for (int u = 0; u <= DEG; ++u)
+#pragma unroll
+      for (int t = u + 1; t <= DEG; ++t) {
+        const bool before = key[t] < key[u];      // ties keep element order, like a stable sort
+        cum[u] += before ? (double)wr[t] : 0.0;
+        cum[t] += before ? 0.0 : (double)wr[u];
+      }
+#pragma unroll
+    for (int t = 0; t < DEG; ++t) {
+      double F1, dF1, F0, dF0;
+      F_dF(xi, cum[t] * inv, F1, dF1);
+      F_dF(xi, (cum[t] - (double)wr[t]) * inv, F0, dF0);
+      gf = fmaf(gi * (float)(dF1 - dF0), key[t], gf);
+      if (kvalid) atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * (float)(F1 - F0));
+    }
+  }
+  if (kvalid && gfreq) atomicAdd(gfreq + k, gf);
+}
+
+__global__ void __launch_bounds__(256) k_embed_reg_weighted_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                                const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
+                                                                int64_t ldp, int S, const float* __restrict__ freqs, float tau,
+                                                                const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
+                                                                float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq) {
+  const int chunk = blockIdx.y * 4 + wave_id();
+  if (chunk * kWave >= S) return;
+  const int k = chunk * kWave + lane_id();
+  const bool kvalid = k < S;
+  const int kc = kvalid ? k : S - 1;
+  int D, p = 0, pe = 0;
+  {
+    int b = blockIdx.x;
+    for (D = FSW_REG_MAX_DEG; D >= 1; --D) {
+      const int lo = bin_start[D], hi = bin_start[D + 1];
+      const int nb = (hi - lo + kBwdRows - 1) / kBwdRows;
+      if (b < nb) {
+        p = lo + b * kBwdRows;
+        pe = min(p + kBwdRows, hi);
+        break;
+      }
+      b -= nb;
+    }
+    if (D < 1) return;
+  }
+  switch (D) {
+#define X(d)                                                                                                                 \
+  case d:                                                                                                                    \
+    weighted_bwd_rows<d>(p, pe, rowptr, col, w, perm, Xp, ldp, freqs, tau, g, ldg, gcol0, out_scale, gXp, ldgp, gfreq, k, kc, \
+                         kvalid);                                                                                            \
+    break;
+    FSW_BWD_CASES(X)
+#undef X
+    default:
+      break;
+  }
+}
+
+int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upper, const float* g, int64_t ldg, float* gXp,
+                          int64_t ldgp, float* gfreq, hipStream_t stream);
+
 }  // namespace fsw
 
 using namespace fsw;
@@ -156,24 +268,36 @@ extern "C" int fsw_unit_dcoeff_table(const float* freqs, int S, int max_deg, flo
 extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
                                       int64_t ldgp, float* gfreq, fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  FSW_REQUIRE(args && dtable && g && gXp, "fsw_embed_backward_f32: null pointer");
+  FSW_REQUIRE(args && g && gXp, "fsw_embed_backward_f32: null pointer");
   const fsw_embed_args& a = *args;
-  FSW_REQUIRE(a.rowptr && a.col && a.perm && a.bin_start && a.Xp && a.unit_table, "fsw_embed_backward_f32: null pointer in args");
-  FSW_REQUIRE(a.w == nullptr && a.tau <= 1.f, "fsw_embed_backward_f32: unit weights with tau <= 1 only (this round)");
-  FSW_REQUIRE(a.num_lds_rows == 0 && a.num_global_rows == 0,
-              "fsw_embed_backward_f32: rows with in-degree > %d are not supported by the backward yet", FSW_REG_MAX_DEG);
-  FSW_REQUIRE(a.S >= 1 && a.ldp >= a.S && a.ldt >= a.S && ldgp >= a.S && ldg >= a.S + a.has_mass, "fsw_embed_backward_f32: bad sizes");
-  if (a.num_reg_rows == 0) return 0;
-  const int64_t rows = a.num_reg_rows < 0 ? a.num_rows : a.num_reg_rows;
-  dim3 grid((unsigned)(ceil_div(rows, kBwdRows) + FSW_REG_MAX_DEG), (unsigned)ceil_div(a.S, 4 * kWave));
-  // long rows first; the two launches differ in the LDS they need for the wave-private coefficient rows
-  k_embed_reg_unit_bwd<17, 32><<<grid, 256, 4 * 2 * 32 * kWave * sizeof(float), stream>>>(
-      a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale, gXp,
-      ldgp, gfreq);
-  FSW_LAUNCH_CHECK();
-  k_embed_reg_unit_bwd<1, 16><<<grid, 256, 4 * 2 * 16 * kWave * sizeof(float), stream>>>(
-      a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale, gXp,
-      ldgp, gfreq);
-  FSW_LAUNCH_CHECK();
+  FSW_REQUIRE(a.rowptr && a.col && a.perm && a.bin_start && a.Xp && a.freqs, "fsw_embed_backward_f32: null pointer in args");
+  FSW_REQUIRE(a.S >= 1 && a.ldp >= a.S && ldgp >= a.S && ldg >= a.S + a.has_mass && a.tau > 0.f, "fsw_embed_backward_f32: bad sizes");
+  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
+  FSW_REQUIRE(!unit_fast || (a.unit_table && dtable && a.ldt >= a.S),
+              "fsw_embed_backward_f32: unit weights with tau <= 1 need unit_table and dtable");
+  const int64_t nreg = a.num_reg_rows < 0 ? a.num_rows : a.num_reg_rows;
+  const int64_t nlds = a.num_lds_rows < 0 ? a.num_rows : a.num_lds_rows;
+  const int64_t nglob = a.num_global_rows < 0 ? a.num_rows : a.num_global_rows;
+  if (nreg > 0) {
+    dim3 grid((unsigned)(ceil_div(nreg, kBwdRows) + FSW_REG_MAX_DEG), (unsigned)ceil_div(a.S, 4 * kWave));
+    if (unit_fast) {
+      // long rows first; the two launches differ in the LDS they need for the wave-private coefficient rows
+      k_embed_reg_unit_bwd<17, 32><<<grid, 256, 4 * 2 * 32 * kWave * sizeof(float), stream>>>(
+          a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale,
+          gXp, ldgp, gfreq);
+      FSW_LAUNCH_CHECK();
+      k_embed_reg_unit_bwd<1, 16><<<grid, 256, 4 * 2 * 16 * kWave * sizeof(float), stream>>>(
+          a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale,
+          gXp, ldgp, gfreq);
+      FSW_LAUNCH_CHECK();
+    } else {
+      k_embed_reg_weighted_bwd<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
+                                                         a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq);
+      FSW_LAUNCH_CHECK();
+    }
+  }
+  int rc;
+  if (nlds > 0 && (rc = launch_embed_long_bwd(a, false, nlds, g, ldg, gXp, ldgp, gfreq, stream))) return rc;
+  if (nglob > 0 && (rc = launch_embed_long_bwd(a, true, nglob, g, ldg, gXp, ldgp, gfreq, stream))) return rc;
   return 0;
 }

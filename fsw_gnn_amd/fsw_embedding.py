@@ -8,8 +8,9 @@ The computation is NOT the reference's chain of torch.sparse_coo operations: for
 sort + cumulative-sum + Fourier readout kernels (fsw_embed_f32).  There is no CPU or pure-PyTorch fallback:
 tensors must live on a HIP device and the native library must be present.
 
-Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kernel, csrc/embed_bwd.hip) for unit
-weights, tau <= 1 and in-degrees <= 32 -- FSW_conv's default configuration; other configurations raise.
+Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kernels, csrc/embed_bwd.hip and
+csrc/embed_lds.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
+total-mass scale (the weights W are constants).
 Not implemented in this round (raise NotImplementedError): d_edge > 0 (edge features), Cartesian mode
 (nSlices x nFreqs), gradients w.r.t. W, mutual-coherence minimisation at initialisation (the flag is accepted,
 slices stay random unit vectors).
@@ -43,20 +44,17 @@ class _EmbedGraphFn(torch.autograd.Function):
     Forward runs the same HIP kernels as inference (prepare + embed_into); backward runs csrc/embed_bwd.hip
     (neighbourhood ranks recomputed in registers, one wave-wide float atomic per neighbour into gXp) and two plain
     GEMMs.  Replaces the reference's chain of sparse autograd Functions (fsw_embedding.py:1232-2257).
-    Supported this round: unit weights, tau <= 1, total_mass_encoding_method 'plain', in-degrees <= 32.
+    Every weight mode and degree class is supported (unit-weight register rows use the float64 coefficient tables, weighted
+    rows and rows above 32 neighbours evaluate the coefficients in float64 on the fly); the weights themselves are
+    constants (no gradient w.r.t. W) and total_mass_encoding_method must be 'plain'.
     """
 
     @staticmethod
     def forward(ctx, X, projVecs, freqs, bias, mass_scale, module, graph, out_scale):
         with torch.no_grad():
-            prepared = module.prepare(X, graph)
-            st = prepared["stats"]
-            if not prepared["unit_fast"]:
-                raise NotImplementedError("fsw_gnn_amd: backward needs unit edge weights and total_mass_pad_thresh <= 1")
-            if st[_lib.STAT_NUM_LDS] or st[_lib.STAT_NUM_GLOBAL]:
-                raise NotImplementedError("fsw_gnn_amd: backward does not support in-degrees > %d yet" % _lib.REG_MAX_DEG)
             if module.encode_total_mass and module.total_mass_encoding_method != 'plain':
                 raise NotImplementedError("fsw_gnn_amd: backward supports total_mass_encoding_method='plain' only")
+            prepared = module.prepare(X, graph)
             out = torch.empty((graph.num_rows, module.d_out), dtype=X.dtype, device=X.device)
             module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
         ctx.module, ctx.graph, ctx.prepared, ctx.out_scale = module, graph, prepared, float(out_scale)
@@ -76,11 +74,16 @@ class _EmbedGraphFn(torch.autograd.Function):
         need_xp = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         if need_xp or ctx.needs_input_grad[2]:
             gXp = torch.zeros((X.shape[0], ldp), dtype=torch.float32, device=X.device)
-            dtable = torch.empty_like(table)
             fr = freqs.detach()
-            _lib.check(L.fsw_unit_dcoeff_table(_lib.ptr(fr), S, _lib.REG_MAX_DEG, _lib.ptr(dtable), ldp, stream), "fsw_unit_dcoeff_table")
+            dtable = None
+            if prepared["unit_fast"]:
+                dtable = torch.empty_like(table)
+                _lib.check(L.fsw_unit_dcoeff_table(_lib.ptr(fr), S, _lib.REG_MAX_DEG, _lib.ptr(dtable), ldp, stream), "fsw_unit_dcoeff_table")
+            scratch = None
+            if st[_lib.STAT_NUM_GLOBAL] > 0:
+                scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=X.device)
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
-            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass)
+            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch)
             _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
                                                 _lib.ptr(gf), stream), "fsw_embed_backward_f32")
             if ctx.needs_input_grad[0]:
@@ -92,7 +95,12 @@ class _EmbedGraphFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             gbias = out_scale * g[:, :module.d_out].sum(dim=0)
         if ctx.needs_input_grad[4]:
-            m = graph.in_degrees()                                         # unit weights: total mass = in-degree
+            deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+            if graph.w is None:
+                m = deg.to(torch.float32)                                  # unit weights: total mass = in-degree
+            else:
+                rows = torch.repeat_interleave(torch.arange(graph.num_rows, device=X.device), deg)
+                m = torch.zeros(graph.num_rows, dtype=torch.float32, device=X.device).index_add_(0, rows, graph.w[:rows.numel()])
             fn = module.total_mass_encoding_function
             fm = m if fn == 'identity' else (2 * (m / (torch.sqrt(m + 1) + 1)) if fn == 'sqrt' else torch.log1p(m))
             gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())

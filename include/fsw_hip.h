@@ -163,15 +163,18 @@ int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const 
 int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
                        const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
 
-/* ---- backward of the fused neighbourhood kernel (unit weights, tau <= 1, degrees <= FSW_REG_MAX_DEG) ---
+/* ---- backward of the fused neighbourhood kernels (every weight mode and degree class) -----------------
  * Replaces the reverse-mode chain of the reference's sparse autograd Functions (ag.*.backward, reference
  * fsw_embedding.py:1284-2257; reverse segcumsum :2158-2172; scatter-unsort :2055-2070).  Given the output
  * gradient g [num_rows, ldg] (column has_mass + k belongs to slice k; the same args as the forward, args->out
  * ignored) it ACCUMULATES
  *   gXp[j, k]  += out_scale * sum over edges j->i of g[i,k] * C[D_i][rank_ik(j)][k]      (gXp zeroed by the caller)
  *   gfreq[k]   += out_scale * sum_i g[i,k] * sum_t dC[D_i][t][k] * p_(t)                  (nullable)
- * with dC = dC/dxi from fsw_unit_dcoeff_table (same layout as fsw_unit_coeff_table).  The gradients of X and
- * projVecs follow as two plain GEMMs: gX = gXp . projVecs, gprojVecs = gXp^T . X.                        */
+ * with dC = dC/dxi from fsw_unit_dcoeff_table (same layout as fsw_unit_coeff_table; used on the unit-weight
+ * register path, may be NULL otherwise -- weighted rows and rows above FSW_REG_MAX_DEG evaluate the
+ * coefficients in float64 on the fly; args->scratch as for fsw_embed_f32 when num_global_rows != 0).  The
+ * weights are constants (no gradient w.r.t. w).  The gradients of X and projVecs follow as two plain GEMMs:
+ * gX = gXp . projVecs, gprojVecs = gXp^T . X.                                                              */
 int fsw_unit_dcoeff_table(const float* freqs, int S, int max_deg, float* dtable, int64_t ldt, fsw_stream_t stream);
 int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
                            int64_t ldgp, float* gfreq, fsw_stream_t stream);

@@ -393,10 +393,50 @@ def test_backward_tiny_graph_vs_reference_autograd(dev):
     assert relerr(E.freqs.grad.cpu().numpy(), gg["gfreqs_unit"]) < 2e-5
     assert relerr(E.bias.grad.cpu().numpy(), gg["gbias_unit"]) < 1e-6
     assert abs(float(E.total_mass_encoding_scale.grad) - float(gg["gscale_unit"])) < 1e-5 * abs(float(gg["gscale_unit"]))
-    # unsupported configurations fail loudly instead of returning wrong gradients
+    # explicit non-unit sparse weights (rows below tau get the pad element): weighted backward kernel
+    E.zero_grad()
+    X2 = t(g["X"], dev).requires_grad_(True)
     adj3 = sparse_adj(g["adj_indices"], g["adj3_values"], (64, 64), dev)
+    out3 = E(X2, adj3, graph_mode=True)
+    assert relerr(out3.detach().cpu().numpy(), gg["out_weighted"]) < TOL
+    (out3 * t(gg["R"], dev)).sum().backward()
+    assert relerr(X2.grad.cpu().numpy(), gg["gX_weighted"]) < 2e-5
+    assert relerr(E.projVecs.grad.cpu().numpy(), gg["gV_weighted"]) < 2e-5
+    assert relerr(E.freqs.grad.cpu().numpy(), gg["gfreqs_weighted"]) < 2e-5
+    assert abs(float(E.total_mass_encoding_scale.grad) - float(gg["gscale_weighted"])) < 1e-5 * abs(float(gg["gscale_weighted"]))
+    # gradients w.r.t. the weights are not provided: fail loudly
     with pytest.raises(NotImplementedError):
-        E(X, adj3, graph_mode=True)
+        E(X2, adj3.to_dense().requires_grad_(True), graph_mode=True)
+
+
+def test_backward_long_rows_lds_and_global_paths(dev):
+    """Readout-shaped input (segments of 700 / 3000 / 5000 points), unit and weighted: LDS and global backward kernels
+    against the oracle's analytic backward evaluated with the same float32 sort order."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(13)
+    sizes = [700, 3000, 5000]
+    n, d, S = sum(sizes), 16, 24
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=83)
+    fr = cases.random_freqs(S, seed=84)
+    gi = np.repeat(np.arange(3), sizes).astype(np.int64)
+    wts = (rng.random(n) + 0.1).astype(np.float32)
+    wts[gi == 0] *= 0.5 / wts[gi == 0].sum()
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    col = np.arange(n)
+    R = rng.standard_normal((3, S))
+    for weights in (None, wts):
+        E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+        Xd = t(X, dev).requires_grad_(True)
+        graph = build_csr(t(gi, dev, torch.int64), t(col, dev, torch.int64), None if weights is None else t(weights, dev), 3, n)
+        out = E.embed_autograd(Xd, graph)
+        (out * t(R, dev)).sum().backward()
+        wv = np.ones(n) if weights is None else weights.astype(np.float64)
+        gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, col, wv, V, fr, R, Xp_override=_hip_projection(E, Xd))
+        assert relerr(out.detach().cpu().numpy(), C.embed(X, rowptr, col, weights, V, fr)) < TOL
+        assert relerr(Xd.grad.cpu().numpy(), gX) < 2e-5
+        assert relerr(E.projVecs.grad.cpu().numpy(), gV) < 2e-5
+        assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
 
 
 def test_backward_conv10k_training_step(dev):
