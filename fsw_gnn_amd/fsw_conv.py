@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .coherence import minimize_mutual_coherence
 from .fsw_embedding import FSW_embedding
 from .graph import build_csr
 
@@ -102,9 +103,8 @@ class FSW_conv(_Base):
             self.mlp = None
             if concat_self:
                 with torch.no_grad():
-                    # the reference additionally runs minimize_mutual_coherence on this matrix (init-time only)
                     dim_reduct = torch.randn(size=(out_channels, mlp_input_dim), device=device, dtype=dtype)
-                    dim_reduct = torch.nn.functional.normalize(dim_reduct, dim=1)
+                    dim_reduct = minimize_mutual_coherence(dim_reduct, report=False)          # fsw_conv.py:260-262
                 self.dim_reduct = torch.nn.Parameter(dim_reduct, requires_grad=learnable_embedding)
             self.bn_final = torch.nn.BatchNorm1d(num_features=out_channels, device=device, dtype=dtype) if batchNorm_final else None
         else:                                                                # fsw_conv.py:269-310

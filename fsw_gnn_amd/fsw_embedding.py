@@ -12,8 +12,7 @@ Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kerne
 csrc/embed_lds.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
 total-mass scale (the weights W are constants).
 Not implemented in this round (raise NotImplementedError): d_edge > 0 (edge features), Cartesian mode
-(nSlices x nFreqs), gradients w.r.t. W, mutual-coherence minimisation at initialisation (the flag is accepted,
-slices stay random unit vectors).
+(nSlices x nFreqs), gradients w.r.t. W.
 """
 import ctypes
 import numbers
@@ -23,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .coherence import minimize_mutual_coherence
 from .graph import CSRGraph, build_csr
 
 version = "0.1-mi355x"
@@ -212,7 +212,8 @@ class FSW_embedding(nn.Module):
         projVecs, freqs, bias, scale = FSW_embedding.generate_embedding_parameters(
             d_in=self.d_in + self.d_edge, nSlices=self.nSlices, nFreqs=self.nFreqs,
             total_mass_encoding_dim=self.total_mass_encoding_dim,
-            total_mass_encoding_scale_init=self.total_mass_encoding_scale_init, freqs_init=self.freqs_init, device=device)
+            total_mass_encoding_scale_init=self.total_mass_encoding_scale_init, freqs_init=self.freqs_init, device=device,
+            minimize_slice_coherence=self.minimize_slice_coherence, report=self.report_on_coherence_minimization)
         self.projVecs = nn.Parameter(projVecs.to(dtype=dtype, device=device), requires_grad=self.learnable_slices)
         self.freqs = nn.Parameter(freqs.to(dtype=dtype, device=device), requires_grad=self.learnable_freqs)
         if self.enable_bias:
@@ -223,12 +224,14 @@ class FSW_embedding(nn.Module):
 
     @staticmethod
     def generate_embedding_parameters(d_in, nSlices, nFreqs, total_mass_encoding_dim, total_mass_encoding_scale_init,
-                                      freqs_init, device):
+                                      freqs_init, device, minimize_slice_coherence=False, report=False):
         dt = torch.float64
-        # A. random unit projection vectors (reference :448-456).  minimize_mutual_coherence (:464, :3045-3248) is
-        #    an init-time O(S^2 d) optimisation outside the hot path and is not ported.
+        # A. random unit projection vectors (reference :448-456), optionally spread out by mutual-coherence
+        #    minimisation (:464, :3045-3248 -> coherence.py)
         projVecs = torch.randn(size=(nSlices, d_in), dtype=dt, device=device)
         projVecs = nn.functional.normalize(projVecs, p=2.0, dim=1, eps=0)
+        if minimize_slice_coherence and nSlices > 1 and d_in > 0:
+            projVecs = minimize_mutual_coherence(projVecs, report=report)
         if nSlices > 0 and d_in > 0:
             assert not torch.isinf(projVecs).any(), "Found infs in projVecs"
             assert not torch.isnan(projVecs).any(), "Found nans in projVecs"

@@ -234,6 +234,18 @@ def case_grads(emb, conv):
          gb=C.mlp[0].bias.grad.numpy())
 
 
+def case_coherence(emb):
+    """minimize_mutual_coherence (fsw_embedding.py:3045-3248) on three fixed starting points, float64."""
+    out = {}
+    for name, (n, d, seed) in {"a": (24, 6, 71), "b": (64, 16, 72), "c": (128, 64, 73)}.items():
+        X0 = torch.from_numpy(synth.normal(seed, 1, (n, d), dtype=np.float64))
+        Xr = emb.minimize_mutual_coherence(X0.clone(), report=False)
+        G = Xr @ Xr.t()
+        G.fill_diagonal_(0)
+        out["X0_" + name], out["Xref_" + name], out["mu_" + name] = X0.numpy(), Xr.numpy(), np.array(float(G.abs().max()))
+    save("coherence", **out)
+
+
 def case_er1m(emb, conv, nslices=256, serialize=4):
     # BASELINE config 3: ER-style multigraph 1M nodes / 10M edges, 128 feat, 256 slices (+ degree column)
     t0 = time.time()
@@ -279,10 +291,12 @@ def main():
         case_rmat(emb, conv)
     elif what == "grads":
         case_grads(emb, conv)
+    elif what == "coherence":
+        case_coherence(emb)
     elif what == "er1m":
         timings.update(case_er1m(emb, conv))
     else:
-        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|er1m]")
+        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|coherence|er1m]")
     json.dump(timings, open(timings_path, "w"), indent=1, sort_keys=True)
 
 

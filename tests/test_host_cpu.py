@@ -146,3 +146,22 @@ def test_slice_sharding_allgather_gloo(world, tmp_path):
     outs = [p.communicate(timeout=180) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARD_OK" in outs[0][0]
+
+
+def test_coherence_minimisation_matches_reference():
+    """coherence.py against the reference's minimize_mutual_coherence on the same starting points (float64 goldens)."""
+    from fsw_gnn_amd.coherence import minimize_mutual_coherence, mutual_coherence
+    g = golden("coherence")
+    for name in ("a", "b", "c"):
+        X0 = torch.from_numpy(g["X0_" + name])
+        X = minimize_mutual_coherence(X0.clone())
+        assert torch.allclose(X.norm(dim=1), torch.ones(X.shape[0], dtype=X.dtype), atol=1e-12)
+        mu0, mu, mu_ref = float(mutual_coherence(X0)), float(mutual_coherence(X)), float(g["mu_" + name])
+        assert mu < mu0 and abs(mu - mu_ref) < 1e-6
+        assert float((X - torch.from_numpy(g["Xref_" + name])).abs().max()) < 1e-6
+    # wired into the constructors like the reference (FSW_conv always minimises, fsw_conv.py:321)
+    from fsw_gnn_amd import FSW_conv
+    C = FSW_conv(6, 10, device="cpu")
+    assert C.fsw_embed.minimize_slice_coherence
+    rnd = torch.nn.functional.normalize(torch.randn(19, 6, dtype=torch.float64), dim=1)
+    assert float(mutual_coherence(C.fsw_embed.projVecs.detach().double())) < float(mutual_coherence(rnd))
