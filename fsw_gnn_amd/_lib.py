@@ -15,7 +15,7 @@ REG_MAX_DEG = 32
 LDS_MAX_DEG = 2048
 NUM_BINS = REG_MAX_DEG + 3
 NUM_STATS = 8
-STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL = 0, 1, 2, 3, 4, 5
+STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL, STAT_NNZ = 0, 1, 2, 3, 4, 5, 6
 FLAG_INDEX_RANGE, FLAG_W_NONFINITE, FLAG_W_NEGATIVE, FLAG_X_NONFINITE = 1, 2, 4, 8
 
 c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -32,6 +32,7 @@ class EmbedArgs(ctypes.Structure):
         ("num_reg_rows", c_i64), ("num_lds_rows", c_i64), ("num_global_rows", c_i64), ("num_zero_rows", c_i64),
         ("max_degree", c_i64),
         ("scratch", c_vp), ("scratch_bytes", c_sz),
+        ("efeat", c_vp), ("Ve", c_vp), ("ldve", c_i64), ("d_edge", c_i32), ("reserved", c_i32),
     ]
 
 
@@ -40,6 +41,8 @@ _SIGNATURES = {
     "fsw_arch": (ctypes.c_char_p, []),
     "fsw_last_error": (ctypes.c_char_p, []),
     "fsw_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "fsw_graph_build_coalesced": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_project_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_unit_table_rows": (c_sz, [ctypes.c_int]),
@@ -53,6 +56,7 @@ _SIGNATURES = {
                                           ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     "fsw_unit_dcoeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_backward_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_embed_backward_keys_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_segcumsum_workspace_bytes": (c_sz, [c_i64]),
     "fsw_segcumsum": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_sz, c_vp]),
     # legacy ABI, exact reference signatures (reference fsw_embedding.py:2952-2977)

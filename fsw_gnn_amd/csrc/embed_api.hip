@@ -34,6 +34,8 @@ extern "C" int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream_) {
   FSW_REQUIRE(a.tau > 0.f, "fsw_embed_f32: total_mass_pad_thresh must be positive");  // reference fsw_embedding.py:637
   FSW_REQUIRE(a.has_mass == 0 || a.has_mass == 1, "fsw_embed_f32: has_mass must be 0 or 1");
   FSW_REQUIRE(a.mass_fn >= 0 && a.mass_fn <= 2, "fsw_embed_f32: mass_fn must be 0, 1 or 2");
+  FSW_REQUIRE(!a.efeat || (a.w && a.Ve && a.d_edge >= 1 && a.ldve >= a.d_edge),
+              "fsw_embed_f32: edge features need a coalesced weighted graph (fsw_graph_build_coalesced) and Ve");
   const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
   FSW_REQUIRE(!unit_fast || (a.unit_table && a.ldt >= a.S), "fsw_embed_f32: unit weights with tau <= 1 need unit_table");
 

@@ -165,7 +165,8 @@ __device__ __forceinline__ void weighted_bwd_rows(int p, int pe, const int32_t* 
                                                   const float* __restrict__ Xp, int64_t ldp, const float* __restrict__ freqs,
                                                   float tau, const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
                                                   float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq, int k, int kc,
-                                                  bool kvalid) {
+                                                  bool kvalid, const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                  int64_t ldve, int d_edge, float* __restrict__ gkey, int64_t ldk) {
   const double xi = (double)freqs[kc];
   float gf = 0.f;
   for (; p < pe; ++p) {
@@ -179,6 +180,11 @@ __device__ __forceinline__ void weighted_bwd_rows(int p, int pe, const int32_t* 
     for (int t = 0; t < DEG; ++t) {
       cidx[t] = col[start + t];
       key[t] = Xp[(int64_t)cidx[t] * ldp + kc];
+      if (efeat) {
+        const float* er = efeat + (int64_t)(start + t) * d_edge;
+        const float* vr = Ve + (int64_t)kc * ldve;
+        for (int q = 0; q < d_edge; ++q) key[t] = fmaf(er[q], vr[q], key[t]);
+      }
       wr[t] = w ? w[start + t] : 1.f;
       m += (double)wr[t];
     }
@@ -203,7 +209,10 @@ __device__ __forceinline__ void weighted_bwd_rows(int p, int pe, const int32_t* 
       F_dF(xi, cum[t] * inv, F1, dF1);
       F_dF(xi, (cum[t] - (double)wr[t]) * inv, F0, dF0);
       gf = fmaf(gi * (float)(dF1 - dF0), key[t], gf);
-      if (kvalid) atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * (float)(F1 - F0));
+      if (kvalid) {
+        if (gkey) gkey[(int64_t)(start + t) * ldk + k] = gi * (float)(F1 - F0);   // edge features: per-entry key gradient
+        else atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * (float)(F1 - F0));
+      }
     }
   }
   if (kvalid && gfreq) atomicAdd(gfreq + k, gf);
@@ -214,7 +223,9 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted_bwd(const int32_t* _
                                                                 const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
                                                                 int64_t ldp, int S, const float* __restrict__ freqs, float tau,
                                                                 const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
-                                                                float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq) {
+                                                                float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
+                                                                const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                                int64_t ldve, int d_edge, float* __restrict__ gkey, int64_t ldk) {
   const int chunk = blockIdx.y * 4 + wave_id();
   if (chunk * kWave >= S) return;
   const int k = chunk * kWave + lane_id();
@@ -239,7 +250,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted_bwd(const int32_t* _
 #define X(d)                                                                                                                 \
   case d:                                                                                                                    \
     weighted_bwd_rows<d>(p, pe, rowptr, col, w, perm, Xp, ldp, freqs, tau, g, ldg, gcol0, out_scale, gXp, ldgp, gfreq, k, kc, \
-                         kvalid);                                                                                            \
+                         kvalid, efeat, Ve, ldve, d_edge, gkey, ldk);                                                        \
     break;
     FSW_BWD_CASES(X)
 #undef X
@@ -249,7 +260,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted_bwd(const int32_t* _
 }
 
 int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upper, const float* g, int64_t ldg, float* gXp,
-                          int64_t ldgp, float* gfreq, hipStream_t stream);
+                          int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream);
 
 }  // namespace fsw
 
@@ -265,16 +276,18 @@ extern "C" int fsw_unit_dcoeff_table(const float* freqs, int S, int max_deg, flo
   return 0;
 }
 
-extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
-                                      int64_t ldgp, float* gfreq, fsw_stream_t stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  FSW_REQUIRE(args && g && gXp, "fsw_embed_backward_f32: null pointer");
+static int embed_backward_impl(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
+                               int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
+  FSW_REQUIRE(args && g && (gXp || gkey), "fsw_embed_backward: null pointer");
   const fsw_embed_args& a = *args;
-  FSW_REQUIRE(a.rowptr && a.col && a.perm && a.bin_start && a.Xp && a.freqs, "fsw_embed_backward_f32: null pointer in args");
-  FSW_REQUIRE(a.S >= 1 && a.ldp >= a.S && ldgp >= a.S && ldg >= a.S + a.has_mass && a.tau > 0.f, "fsw_embed_backward_f32: bad sizes");
-  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
+  FSW_REQUIRE(a.rowptr && a.col && a.perm && a.bin_start && a.Xp && a.freqs, "fsw_embed_backward: null pointer in args");
+  FSW_REQUIRE(a.S >= 1 && a.ldp >= a.S && ldg >= a.S + a.has_mass && a.tau > 0.f, "fsw_embed_backward: bad sizes");
+  FSW_REQUIRE(gkey ? ldk >= a.S : ldgp >= a.S, "fsw_embed_backward: bad gradient stride");
+  FSW_REQUIRE(!a.efeat || (a.w && a.Ve && a.d_edge >= 1 && a.ldve >= a.d_edge && gkey),
+              "fsw_embed_backward: edge features need a coalesced weighted graph, Ve and the key-gradient form");
+  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f) && !gkey;
   FSW_REQUIRE(!unit_fast || (a.unit_table && dtable && a.ldt >= a.S),
-              "fsw_embed_backward_f32: unit weights with tau <= 1 need unit_table and dtable");
+              "fsw_embed_backward: unit weights with tau <= 1 need unit_table and dtable");
   const int64_t nreg = a.num_reg_rows < 0 ? a.num_rows : a.num_reg_rows;
   const int64_t nlds = a.num_lds_rows < 0 ? a.num_rows : a.num_lds_rows;
   const int64_t nglob = a.num_global_rows < 0 ? a.num_rows : a.num_global_rows;
@@ -292,12 +305,25 @@ extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* d
       FSW_LAUNCH_CHECK();
     } else {
       k_embed_reg_weighted_bwd<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
-                                                         a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq);
+                                                         a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq, a.efeat, a.Ve,
+                                                         a.ldve, a.d_edge, gkey, ldk);
       FSW_LAUNCH_CHECK();
     }
   }
   int rc;
-  if (nlds > 0 && (rc = launch_embed_long_bwd(a, false, nlds, g, ldg, gXp, ldgp, gfreq, stream))) return rc;
-  if (nglob > 0 && (rc = launch_embed_long_bwd(a, true, nglob, g, ldg, gXp, ldgp, gfreq, stream))) return rc;
+  if (nlds > 0 && (rc = launch_embed_long_bwd(a, false, nlds, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc;
+  if (nglob > 0 && (rc = launch_embed_long_bwd(a, true, nglob, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc;
   return 0;
+}
+
+extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
+                                      int64_t ldgp, float* gfreq, fsw_stream_t stream) {
+  FSW_REQUIRE(gXp, "fsw_embed_backward_f32: null gXp");
+  return embed_backward_impl(args, dtable, g, ldg, gXp, ldgp, gfreq, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int64_t ldg, float* gkey, int64_t ldk,
+                                           float* gfreq, fsw_stream_t stream) {
+  FSW_REQUIRE(gkey, "fsw_embed_backward_keys_f32: null gkey");
+  return embed_backward_impl(args, nullptr, g, ldg, nullptr, 0, gfreq, gkey, ldk, reinterpret_cast<hipStream_t>(stream));
 }

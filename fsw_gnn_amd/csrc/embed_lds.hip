@@ -79,6 +79,18 @@ struct Elem<true> {
   static __device__ __forceinline__ int idx(type e) { return (int)(uint32_t)e; }
 };
 
+// key of CSR entry e for slice k: projected sender feature (+ projected edge feature, reference fsw_embedding.py:934-968)
+__device__ __forceinline__ float long_key(const float* __restrict__ Xp, int64_t ldp, const int32_t* __restrict__ col, int e, int k,
+                                          const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve, int d_edge) {
+  float key = Xp[(int64_t)col[e] * ldp + k];
+  if (efeat) {
+    const float* er = efeat + (int64_t)e * d_edge;
+    const float* vr = Ve + (int64_t)k * ldve;
+    for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+  }
+  return key;
+}
+
 // All threads of the workgroup: bitonic sort of `nlines` lines of Dp elements each, line stride `ls`.
 template <class T>
 __device__ __forceinline__ void bitonic_lines(T* tile, int nlines, int Dp, int ls) {
@@ -110,7 +122,9 @@ __global__ void __launch_bounds__(256) k_embed_long(const int32_t* __restrict__ 
                                                     int64_t ldp, int S, const float* __restrict__ freqs, float tau,
                                                     float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
                                                     float out_scale, int has_mass, int mass_fn, float mass_scale,
-                                                    char* __restrict__ scratch, int64_t scratch_per_wg) {
+                                                    char* __restrict__ scratch, int64_t scratch_per_wg,
+                                                    const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve,
+                                                    int d_edge) {
   using E = Elem<WEIGHTED>;
   using T = typename E::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,7 +194,7 @@ __global__ void __launch_bounds__(256) k_embed_long(const int32_t* __restrict__ 
         T e = E::pad();
         if (t < D) {
           const int kcl = min(k0 + kk, S - 1);
-          e = E::make(Xp[(int64_t)col[start + t] * ldp + kcl], t);
+          e = E::make(long_key(Xp, ldp, col, start + t, kcl, efeat, Ve, ldve, d_edge), t);
         } else if (WEIGHTED && t == D) {
           e = E::make(0.f, t);  // pad element at x = 0
         }
@@ -274,7 +288,9 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
                                                         int64_t ldp, int S, const float* __restrict__ freqs, float tau,
                                                         const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
                                                         float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
-                                                        char* __restrict__ scratch, int64_t scratch_per_wg) {
+                                                        char* __restrict__ scratch, int64_t scratch_per_wg,
+                                                        const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve,
+                                                        int d_edge, float* __restrict__ gkey, int64_t ldk) {
   using E = Elem<true>;
   using T = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -332,7 +348,7 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
         const int kk = i % SC, t = i / SC;
         T e = E::pad();
         if (t < D) {
-          e = E::make(Xp[(int64_t)col[start + t] * ldp + min(k0 + kk, S - 1)], t);
+          e = E::make(long_key(Xp, ldp, col, start + t, min(k0 + kk, S - 1), efeat, Ve, ldve, d_edge), t);
         } else if (WEIGHTED && t == D) {
           e = E::make(0.f, t);
         }
@@ -387,7 +403,10 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
       __syncthreads();
       for (int i = threadIdx.x; i < D * SC; i += blockDim.x) {
         const int kk = i % SC, t = i / SC;
-        if (k0 + kk < S) atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k0 + kk, tc[(int64_t)kk * ls + t]);
+        if (k0 + kk < S) {
+          if (gkey) gkey[(int64_t)(start + t) * ldk + k0 + kk] = tc[(int64_t)kk * ls + t];   // edge features: per-entry key gradient
+          else atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k0 + kk, tc[(int64_t)kk * ls + t]);
+        }
       }
       __syncthreads();
     }
@@ -395,7 +414,7 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
 }
 
 int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upper, const float* g, int64_t ldg, float* gXp,
-                          int64_t ldgp, float* gfreq, hipStream_t stream) {
+                          int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
   const bool unit = (a.w == nullptr) && (a.tau <= 1.f);
   char* scratch = reinterpret_cast<char*>(a.scratch);
@@ -409,7 +428,8 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
 #define FSW_LAUNCH_LONG_BWD(WGT, GLB)                                                                                          \
   k_embed_long_bwd<WGT, GLB><<<grid, 256, (GLB) ? 1024 : kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, \
                                                                              a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass,   \
-                                                                             a.out_scale, gXp, ldgp, gfreq, scratch, per_wg)
+                                                                             a.out_scale, gXp, ldgp, gfreq, scratch, per_wg,   \
+                                                                             a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk)
   if (global) {
     if (unit) FSW_LAUNCH_LONG_BWD(false, true);
     else FSW_LAUNCH_LONG_BWD(true, true);
@@ -438,11 +458,11 @@ int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
   if (unit_fast)
     k_embed_long<false, false><<<grid, 256, kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
                                                                  a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,
-                                                                 a.mass_fn, a.mass_scale, nullptr, 0);
+                                                                 a.mass_fn, a.mass_scale, nullptr, 0, a.efeat, a.Ve, a.ldve, a.d_edge);
   else
     k_embed_long<true, false><<<grid, 256, kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
                                                                 a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,
-                                                                a.mass_fn, a.mass_scale, nullptr, 0);
+                                                                a.mass_fn, a.mass_scale, nullptr, 0, a.efeat, a.Ve, a.ldve, a.d_edge);
   FSW_LAUNCH_CHECK();
   return 0;
 }
@@ -459,11 +479,11 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
   if (unit_fast)
     k_embed_long<false, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
                                                            a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                           a.mass_scale, scratch, per_wg);
+                                                           a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge);
   else
     k_embed_long<true, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
                                                           a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                          a.mass_scale, scratch, per_wg);
+                                                          a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge);
   FSW_LAUNCH_CHECK();
   return 0;
 }

@@ -159,7 +159,8 @@ __device__ __forceinline__ void weighted_run(int p, int pe, const int32_t* __res
                                              const float* __restrict__ Xp, int64_t ldp, const float* __restrict__ freqs,
                                              float tau, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
                                              float out_scale, int has_mass, int mass_fn, float mass_scale, int k, int kc,
-                                             bool kvalid, bool mass_lane) {
+                                             bool kvalid, bool mass_lane, const float* __restrict__ efeat,
+                                             const float* __restrict__ Ve, int64_t ldve, int d_edge) {
   const float xif = freqs[kc];
   const double xi = (double)xif;
   const bool lin = xif < 1e-30f;  // xi == 0: sinc(0) = 1 and cos(0) = 1, Delta_t = 2 w_t
@@ -175,7 +176,13 @@ __device__ __forceinline__ void weighted_run(int p, int pe, const int32_t* __res
     for (int t = 0; t < DEG; ++t) {
       const int c = col[start + t];
       const float wt = w ? w[start + t] : 1.f;
-      net.k[t] = Xp[(int64_t)c * ldp + kc];
+      float key = Xp[(int64_t)c * ldp + kc];
+      if (efeat) {   // edge features: + <e_ij, v_k[d_in:]>, the feature row is wave-uniform (reference fsw_embedding.py:934-968)
+        const float* er = efeat + (int64_t)(start + t) * d_edge;
+        const float* vr = Ve + (int64_t)kc * ldve;
+        for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+      }
+      net.k[t] = key;
       net.w[t] = wt;
       m += (double)wt;
     }
@@ -207,7 +214,9 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted(const int32_t* __res
                                                             const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
                                                             int64_t ldp, int S, const float* __restrict__ freqs, float tau,
                                                             float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
-                                                            float out_scale, int has_mass, int mass_fn, float mass_scale) {
+                                                            float out_scale, int has_mass, int mass_fn, float mass_scale,
+                                                            const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                            int64_t ldve, int d_edge) {
   const int chunk = blockIdx.y * 4 + wave_id();
   if (chunk * kWave >= S) return;
   const int k = chunk * kWave + lane_id();
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted(const int32_t* __res
 #define X(d)                                                                                                          \
   case d:                                                                                                             \
     weighted_run<d>(p, pe, rowptr, col, w, perm, Xp, ldp, freqs, tau, out, ldo, bias, out_scale, has_mass, mass_fn,   \
-                    mass_scale, k, kc, kvalid, mass_lane);                                                            \
+                    mass_scale, k, kc, kvalid, mass_lane, efeat, Ve, ldve, d_edge);                                   \
     break;
     FSW_CASES_1_32(X)
 #undef X
@@ -251,7 +260,8 @@ int launch_embed_reg(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
                                                a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
   else
     k_embed_reg_weighted<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau,
-                                                   a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+                                                   a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve,
+                                                   a.d_edge);
   FSW_LAUNCH_CHECK();
   return 0;
 }

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_upsweep(const int64_t* __rest
 }
 
 // VAL = uint32_t (sender) for unit weights, uint64_t (sender | weight bits << 32) when weights are carried
-template <bool FIRST, class VAL>
+template <bool FIRST, class VAL, bool EID = false>   // EID: carry the edge id instead of the sender
 __global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __restrict__ recipients,
                                                              const int64_t* __restrict__ senders,
                                                              const float* __restrict__ edge_w,
@@ -203,7 +203,9 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __re
     val[i] = VAL(0);
     if (ok) {
       key[i] = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, dummy);
-      if constexpr (FIRST) {
+      if constexpr (FIRST && EID) {
+        val[i] = (VAL)(uint32_t)e;
+      } else if constexpr (FIRST) {
         const uint32_t s = (uint32_t)senders[e];
         if constexpr (sizeof(VAL) == 8)
           val[i] = (VAL)s | ((VAL)__float_as_uint(edge_w[e]) << 32);
@@ -421,43 +423,131 @@ static GraphWs carve(void* ws, int64_t num_edges) {
   return g;
 }
 
-template <class VAL>
-static int sort_and_finish(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
-                           int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* stats,
-                           GraphWs& g, hipStream_t stream) {
+// LSD radix sort of E (key, value) pairs.  first_a / first_b: the int64 arrays the FIRST pass reads directly
+// (key = first_a[e], valid when 0 <= first_a[e] < range_a and 0 <= first_b[e] < range_b; invalid edges get the
+// sentinel key range_a and sort last).  keys_in != NULL: pre-built uint32 keys instead (values from g.vals[*cur]).
+// On return *cur selects the ping-pong buffer that holds the result.
+template <class VAL, bool EID>
+static int radix_sort_pairs(const int64_t* first_a, const int64_t* first_b, const float* edge_w, bool from_keys,
+                            int64_t num_edges, int64_t range_a, int64_t range_b, int32_t* stats, GraphWs& g, int* cur_io,
+                            hipStream_t stream) {
   int keybits = 1;
-  while ((1ll << keybits) <= num_rows) ++keybits;  // values 0 .. num_rows (sentinel) must fit
+  while ((1ll << keybits) <= range_a) ++keybits;  // values 0 .. range_a (sentinel) must fit
   const int npass = (keybits + 7) / 8;
   const int bits = (keybits + npass - 1) / npass;
   const int64_t ntiles = ceil_div(num_edges, kRsTile);
-  int cur = 0;
+  int cur = *cur_io;
   for (int pass = 0; pass < npass; ++pass) {
     const int shift = pass * bits;
     const int ndigits = 1 << bits;
+    const bool first = (pass == 0) && !from_keys;
     const uint32_t* kin = g.keys[cur];
     const VAL* vin = reinterpret_cast<const VAL*>(g.vals[cur]);
     uint32_t* kout = g.keys[cur ^ 1];
     VAL* vout = reinterpret_cast<VAL*>(g.vals[cur ^ 1]);
-    if (pass == 0)
-      k_rs_upsweep<true><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(recipients, senders, edge_w, nullptr, num_edges, num_rows,
-                                                                      num_cols, shift, ndigits, g.counts, ntiles, stats);
+    if (first)
+      k_rs_upsweep<true><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(first_a, first_b, edge_w, nullptr, num_edges, range_a,
+                                                                      range_b, shift, ndigits, g.counts, ntiles, stats);
     else
-      k_rs_upsweep<false><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, num_edges, num_rows,
-                                                                       num_cols, shift, ndigits, g.counts, ntiles, stats);
+      k_rs_upsweep<false><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, num_edges, range_a,
+                                                                       range_b, shift, ndigits, g.counts, ntiles, stats);
     FSW_LAUNCH_CHECK();
     int rc = exclusive_scan_i32(g.counts, (int64_t)ndigits * ntiles, g.block_sums, stream);
     if (rc) return rc;
-    if (pass == 0)
-      k_rs_downsweep<true, VAL><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(recipients, senders, edge_w, nullptr, nullptr, num_edges,
-                                                                             num_rows, num_cols, shift, bits, g.counts, ntiles, kout, vout);
+    if (first)
+      k_rs_downsweep<true, VAL, EID><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(first_a, first_b, edge_w, nullptr, nullptr, num_edges,
+                                                                                  range_a, range_b, shift, bits, g.counts, ntiles, kout, vout);
     else
-      k_rs_downsweep<false, VAL><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, vin, num_edges, num_rows,
-                                                                              num_cols, shift, bits, g.counts, ntiles, kout, vout);
+      k_rs_downsweep<false, VAL, EID><<<(unsigned)ntiles, kRsThreads, 0, stream>>>(nullptr, nullptr, nullptr, kin, vin, num_edges, range_a,
+                                                                                   range_b, shift, bits, g.counts, ntiles, kout, vout);
     FSW_LAUNCH_CHECK();
     cur ^= 1;
   }
+  *cur_io = cur;
+  return 0;
+}
+
+template <class VAL>
+static int sort_and_finish(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                           int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* stats,
+                           GraphWs& g, hipStream_t stream) {
+  int cur = 0;
+  int rc = radix_sort_pairs<VAL, false>(recipients, senders, edge_w, false, num_edges, num_rows, num_cols, stats, g, &cur, stream);
+  if (rc) return rc;
   const int blocks = (int)std::min<int64_t>(ceil_div(num_edges + 1, 256), 256 * 32);
   k_finish_csr<VAL><<<blocks, 256, 0, stream>>>(g.keys[cur], reinterpret_cast<const VAL*>(g.vals[cur]), num_edges, num_rows, rowptr, col, w);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- coalescing build (edge features; exact reference adjacency) ----------------------------------------------------
+// Sort by (recipient, sender) = stable sort by sender, then stable sort by recipient, carrying the edge id; a run of equal
+// (recipient, sender) pairs becomes ONE CSR entry whose weight and feature vector are the sums over the run -- what
+// torch.sparse_coo_tensor(...).coalesce() does to adj and X_edge in the reference (fsw_conv.py:397-398, 436-437).
+__global__ void __launch_bounds__(256) k_gather_keys(const int64_t* __restrict__ recipients, const uint32_t* __restrict__ eid,
+                                                     const uint32_t* __restrict__ sender_keys, int64_t num_edges, int64_t num_rows,
+                                                     int64_t num_cols, uint32_t* __restrict__ keys_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = recipients[eid[i]];
+    // an edge whose sender was out of range carries the sentinel sender key: keep it invalid
+    keys_out[i] = (r < 0 || r >= num_rows || sender_keys[i] >= (uint32_t)num_cols) ? (uint32_t)num_rows : (uint32_t)r;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mark_heads(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ eid,
+                                                    const int64_t* __restrict__ senders, int64_t num_edges, int64_t num_rows,
+                                                    int32_t* __restrict__ head) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool valid = keys[i] < (uint32_t)num_rows;
+    const bool differs = i == 0 || keys[i] != keys[i - 1] || senders[eid[i]] != senders[eid[i - 1]];
+    head[i] = (valid && differs) ? 1 : 0;
+  }
+}
+
+// pos = exclusive scan of head.  One thread per run head sums the run (duplicates are rare and short) in edge-list order.
+__global__ void __launch_bounds__(256) k_emit_coalesced(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ eid,
+                                                        const int32_t* __restrict__ head, const int32_t* __restrict__ pos,
+                                                        const int64_t* __restrict__ senders, const float* __restrict__ edge_w,
+                                                        const float* __restrict__ edge_feat, int d_edge, int64_t num_edges,
+                                                        int64_t num_rows, uint32_t* __restrict__ keyc, int32_t* __restrict__ col,
+                                                        float* __restrict__ w, float* __restrict__ ef,
+                                                        int32_t* __restrict__ slot_of_edge, int32_t* __restrict__ nnz_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i == num_edges - 1) *nnz_out = pos[i] + head[i];
+    if (!head[i]) continue;
+    const int p = pos[i];
+    double wsum = 0.0;
+    for (int q = 0; q < d_edge; ++q) ef[(int64_t)p * d_edge + q] = 0.f;
+    for (int64_t j = i; j < num_edges && (j == i || (!head[j] && keys[j] < (uint32_t)num_rows)); ++j) {
+      const uint32_t e = eid[j];
+      wsum += edge_w ? (double)edge_w[e] : 1.0;
+      for (int q = 0; q < d_edge; ++q) ef[(int64_t)p * d_edge + q] += edge_feat[(int64_t)e * d_edge + q];
+      if (slot_of_edge) slot_of_edge[e] = p;
+    }
+    keyc[p] = keys[i];
+    col[p] = (int32_t)senders[eid[i]];
+    w[p] = (float)wsum;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rowptr_from_keys(const uint32_t* __restrict__ keyc, const int32_t* __restrict__ nnz_ptr,
+                                                          int64_t num_rows, int32_t* __restrict__ rowptr) {
+  const int64_t nnz = *nnz_ptr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = i == 0 ? -1 : (int64_t)keyc[i - 1];
+    const int64_t cur = i == nnz ? num_rows : (int64_t)keyc[i];
+    for (int64_t r = prev + 1; r <= cur && r <= num_rows; ++r) rowptr[r] = (int32_t)i;
+  }
+}
+
+static int finish_bins(int32_t* rowptr, int64_t num_rows, int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats,
+                       GraphWs& g, hipStream_t stream) {
+  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 256 * 16);
+  k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, g.bin_count, stats);
+  FSW_LAUNCH_CHECK();
+  k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
+  FSW_LAUNCH_CHECK();
+  k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
   FSW_LAUNCH_CHECK();
   return 0;
 }
@@ -497,12 +587,60 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
                     : sort_and_finish<uint32_t>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream);
     if (rc) return rc;
   }
-  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 256 * 16);
-  k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, g.bin_count, stats);
+  return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
+}
+
+extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_t* senders, const float* edge_w,
+                                         const float* edge_feat, int d_edge, int64_t num_edges, int64_t num_rows, int64_t num_cols,
+                                         int32_t* rowptr, int32_t* col, float* w, float* ef, int32_t* slot_of_edge, int32_t* perm,
+                                         int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
+                                         size_t workspace_bytes, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) - 1 && num_cols >= 1 && num_cols < (1ll << 31) - 1 && num_edges >= 0 &&
+                  num_edges < (1ll << 31) - kRsTile,
+              "fsw_graph_build_coalesced: sizes must satisfy 1 <= rows, cols < 2^31 and 0 <= edges < 2^31");
+  FSW_REQUIRE(workspace && workspace_bytes >= fsw_graph_workspace_bytes(num_rows, num_edges),
+              "fsw_graph_build_coalesced: workspace too small");
+  FSW_REQUIRE(rowptr && perm && bin_start && stats && w && (num_edges == 0 || (col && recipients && senders)),
+              "fsw_graph_build_coalesced: null pointer");
+  FSW_REQUIRE(d_edge >= 0 && (d_edge == 0 || (edge_feat && ef)), "fsw_graph_build_coalesced: edge features need edge_feat and ef");
+  GraphWs g = carve(workspace, num_edges);
+  FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, 512, stream));
+  FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
+  if (num_edges == 0) {
+    FSW_CHECK_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
+    return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
+  }
+  if (slot_of_edge) FSW_CHECK_HIP(hipMemsetAsync(slot_of_edge, 0xff, sizeof(int32_t) * (size_t)num_edges, stream));
+  const int edge_blocks = (int)std::min<int64_t>(ceil_div(num_edges, 256), 256 * 16);
+  int cur = 0, rc;
+  // 1. stable sort by sender, carrying the edge id (validates both endpoints and the weights)
+  if ((rc = radix_sort_pairs<uint32_t, true>(senders, recipients, edge_w, false, num_edges, num_cols, num_rows, stats, g, &cur, stream))) return rc;
+  // 2. stable sort by recipient: (recipient, sender) order
+  k_gather_keys<<<edge_blocks, 256, 0, stream>>>(recipients, reinterpret_cast<const uint32_t*>(g.vals[cur]), g.keys[cur], num_edges,
+                                                 num_rows, num_cols, g.keys[cur ^ 1]);
   FSW_LAUNCH_CHECK();
-  k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
+  {  // the gathered keys live in the other key buffer: make it the current one, values stay where they are
+    uint32_t* t = g.keys[cur];
+    g.keys[cur] = g.keys[cur ^ 1];
+    g.keys[cur ^ 1] = t;
+  }
+  if ((rc = radix_sort_pairs<uint32_t, true>(nullptr, nullptr, nullptr, true, num_edges, num_rows, num_cols, stats, g, &cur, stream))) return rc;
+  // 3. runs of equal (recipient, sender) -> one entry each
+  const uint32_t* keys = g.keys[cur];
+  const uint32_t* eid = reinterpret_cast<const uint32_t*>(g.vals[cur]);
+  int32_t* head = reinterpret_cast<int32_t*>(g.vals[cur ^ 1]);
+  int32_t* pos = head + num_edges;
+  uint32_t* keyc = g.keys[cur ^ 1];
+  k_mark_heads<<<edge_blocks, 256, 0, stream>>>(keys, eid, senders, num_edges, num_rows, head);
   FSW_LAUNCH_CHECK();
-  k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
+  FSW_CHECK_HIP(hipMemcpyAsync(pos, head, sizeof(int32_t) * (size_t)num_edges, hipMemcpyDeviceToDevice, stream));
+  if ((rc = exclusive_scan_i32(pos, num_edges, g.block_sums, stream))) return rc;
+  int32_t* nnz_dev = stats + FSW_STAT_NNZ;
+  k_emit_coalesced<<<edge_blocks, 256, 0, stream>>>(keys, eid, head, pos, senders, edge_w, edge_feat, d_edge, num_edges, num_rows,
+                                                    keyc, col, w, ef, slot_of_edge, nnz_dev);
   FSW_LAUNCH_CHECK();
-  return 0;
+  k_rowptr_from_keys<<<edge_blocks, 256, 0, stream>>>(keyc, nnz_dev, num_rows, rowptr);
+  FSW_LAUNCH_CHECK();
+  return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
 }

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from .coherence import minimize_mutual_coherence
 from .fsw_embedding import FSW_embedding
-from .graph import build_csr
+from .graph import build_csr, build_csr_coalesced
 
 try:  # optional dependency, exactly the names the reference imports (fsw_conv.py:4-9)
     from torch_geometric.nn import MessagePassing as _Base
@@ -80,8 +80,6 @@ class FSW_conv(_Base):
         assert edge_weighting in {'unit', 'gcn'}, 'invalid value passed in argument <edge_weighting>'
         assert vertex_degree_encoding_function in {'identity', 'sqrt', 'log'}, \
             'invalid value passed in argument <vertex_degree_encoding_function>'
-        if edgefeat_dim > 0:
-            raise NotImplementedError("fsw_gnn_amd: edge features (edgefeat_dim > 0) are not implemented yet (SURVEY.md 8f #2)")
         if mlp_hidden_dim is None:
             mlp_hidden_dim = max(in_channels, out_channels)
         if (mlp_layers == 0) and (concat_self is False):
@@ -151,14 +149,34 @@ class FSW_conv(_Base):
         self.to(device=device, dtype=dtype)
 
     # ------------------------------------------------------------------------------------------------
-    def build_graph(self, edge_index, num_vertices):
+    def build_graph(self, edge_index, num_vertices, edge_features=None):
         """edge_index [2, E] int64 (row 0 = sender, row 1 = recipient) -> CSRGraph.
+
+        With edge features (edgefeat_dim > 0, fsw_conv.py:419-439) the adjacency is coalesced like the reference's:
+        parallel edges become one entry with summed weight and summed feature vector; self loops carry zero features.
 
         Unit weighting without self loops carries no weight array at all (the unit fast path).  Self loops
         (fsw_conv.py:390-395) append n weighted edges; 'gcn' weighting (fsw_conv.py:406-409) divides every
         edge by sqrt(deg_recipient) * sqrt(deg_sender) with deg = weighted in-degree.  Parallel edges stay
         separate elements (see DESIGN.md "duplicates"), which gives the same sums as the reference's coalesce.
         """
+        if edge_features is not None:
+            src, dst = edge_index[0], edge_index[1]
+            ef = edge_features.detach().reshape(src.numel(), -1)
+            w = None
+            if self.self_loop_weight > 0:
+                loops = torch.arange(num_vertices, device=edge_index.device, dtype=torch.int64)
+                w = torch.cat([torch.ones(src.numel(), device=src.device, dtype=torch.float32),
+                               torch.full((num_vertices,), float(self.self_loop_weight), device=src.device, dtype=torch.float32)])
+                src, dst = torch.cat([src, loops]), torch.cat([dst, loops])
+                ef = torch.cat([ef, torch.zeros((num_vertices, ef.shape[1]), device=ef.device, dtype=ef.dtype)])
+            if self.edge_weighting == 'gcn':
+                if w is None:
+                    w = torch.ones(src.numel(), device=src.device, dtype=torch.float32)
+                deg = torch.zeros(num_vertices, device=src.device, dtype=torch.float32).scatter_add_(0, dst, w)
+                ds = torch.sqrt(deg)
+                w = w / ds[dst] / ds[src]
+            return build_csr_coalesced(dst, src, w, ef.contiguous(), num_vertices, num_vertices, want_slots=True)
         if self.cache_graph:
             # optional CSR reuse across calls / layers (SURVEY 8f #3).  Off by default: the reference rebuilds its
             # adjacency on every forward (fsw_conv.py:352) and bench.py times the rebuild.
@@ -196,13 +214,24 @@ class FSW_conv(_Base):
         assert vertex_features.dtype == emb_mod.get_dtype(), 'vertex_features has incorrect dtype (expected %s, got %s)' % (emb_mod.get_dtype(), vertex_features.dtype)
         assert vertex_features.device == emb_mod.get_device(), 'vertex_features has incorrect device (expected %s, got %s)' % (emb_mod.get_device(), vertex_features.device)
         assert edge_index.device == emb_mod.get_device(), 'edge_index has incorrect device (expected %s, got %s)' % (emb_mod.get_device(), edge_index.device)
-        assert edge_features is None, 'Edge features should not be provided since edgefeat_dim = 0'
+        if self.edgefeat_dim > 0:
+            num_edges = edge_index.shape[1]
+            assert edge_features is not None, 'Edge features must be provided since edgefeat_dim > 0'
+            assert edge_features.dim() in (1, 2), 'edge_features should have the shape (num_edges, edegfeat_dim) (or optionally (num_edges,) in the case edgefeat_dim=1)'
+            if self.edgefeat_dim == 1:
+                assert tuple(edge_features.shape) in {(num_edges,), (num_edges, 1)}, 'edge_features should have the shape (num_edges, edegfeat_dim) (or optionally (num_edges,) in the case edgefeat_dim=1)'
+            else:
+                assert tuple(edge_features.shape) == (num_edges, self.edgefeat_dim), 'edge_features must have the shape (num_edges, edgefeat_dim)'
+            assert edge_features.dtype == vertex_features.dtype and edge_features.device == vertex_features.device
+        else:
+            assert edge_features is None, 'Edge features should not be provided since edgefeat_dim = 0'
         if vertex_features.device.type != 'cuda':
             raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
-        needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters()))
+        needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                  or (edge_features is not None and edge_features.requires_grad))
         n = vertex_features.size(0)
         x = vertex_features.contiguous()
-        graph = self.build_graph(edge_index, n)
+        graph = self.build_graph(edge_index, n, edge_features if self.edgefeat_dim > 0 else None)
         E = self.embed_dim
         scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
         sharded = getattr(self, '_slice_parallel', False)
@@ -211,7 +240,8 @@ class FSW_conv(_Base):
             # training path: differentiable embedding (HIP forward + backward kernels), the tail through torch autograd
             if sharded:
                 raise NotImplementedError("fsw_gnn_amd: slice-parallel training is not implemented")
-            emb = emb_mod.embed_autograd(x, graph)
+            ef_in = edge_features.reshape(edge_index.shape[1], -1) if self.edgefeat_dim > 0 else None
+            emb = emb_mod.embed_autograd(x, graph, edge_feat=ef_in)
             h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
             out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
             return self.bn_final(out) if self.bn_final is not None else out
@@ -264,7 +294,7 @@ class FSW_conv(_Base):
         emb = self.fsw_embed
         if not (self.fuse_linear and self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear)):
             return False
-        if self.self_loop_weight > 0 or self.edge_weighting != 'unit' or emb.total_mass_pad_thresh > 1.0:
+        if self.self_loop_weight > 0 or self.edge_weighting != 'unit' or emb.total_mass_pad_thresh > 1.0 or self.edgefeat_dim > 0:
             return False
         if emb.encode_total_mass and emb.total_mass_encoding_method != 'plain':
             return False

@@ -11,8 +11,8 @@ tensors must live on a HIP device and the native library must be present.
 Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kernels, csrc/embed_bwd.hip and
 csrc/embed_lds.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
 total-mass scale (the weights W are constants).
-Not implemented in this round (raise NotImplementedError): d_edge > 0 (edge features), Cartesian mode
-(nSlices x nFreqs), gradients w.r.t. W.
+Edge features (d_edge > 0) go through the coalescing CSR build and the general-weight kernels.
+Not implemented (raise NotImplementedError): Cartesian mode (nSlices x nFreqs), gradients w.r.t. W.
 """
 import ctypes
 import numbers
@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import _lib
 from .coherence import minimize_mutual_coherence
-from .graph import CSRGraph, build_csr
+from .graph import CSRGraph, build_csr, build_csr_coalesced
 
 version = "0.1-mi355x"
 
@@ -38,6 +38,10 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+def edge_feat_rows(ctx):
+    return ctx.num_edge_rows
+
+
 class _EmbedGraphFn(torch.autograd.Function):
     """out = out_scale * E(X, graph) with gradients for X, projVecs, freqs, bias and the total-mass scale.
 
@@ -50,7 +54,7 @@ class _EmbedGraphFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, X, projVecs, freqs, bias, mass_scale, module, graph, out_scale):
+    def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale):
         with torch.no_grad():
             if module.encode_total_mass and module.total_mass_encoding_method != 'plain':
                 raise NotImplementedError("fsw_gnn_amd: backward supports total_mass_encoding_method='plain' only")
@@ -58,6 +62,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             out = torch.empty((graph.num_rows, module.d_out), dtype=X.dtype, device=X.device)
             module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
         ctx.module, ctx.graph, ctx.prepared, ctx.out_scale = module, graph, prepared, float(out_scale)
+        ctx.num_edge_rows = 0 if edge_feat is None else edge_feat.shape[0]
         ctx.save_for_backward(X, projVecs, freqs)
         return out
 
@@ -72,7 +77,33 @@ class _EmbedGraphFn(torch.autograd.Function):
         ldp, Xp, table, st = prepared["ldp"], prepared["Xp"], prepared["table"], prepared["stats"]
         gX = gV = gfreqs = gbias = gscale = None
         need_xp = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        if need_xp or ctx.needs_input_grad[2]:
+        gEf = None
+        if graph.ef is not None and (need_xp or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]):
+            # edge features: the kernels store the gradient of every key; everything else is index_add + three GEMMs
+            nnz = st[_lib.STAT_NNZ]
+            fr = freqs.detach()
+            scratch = None
+            if st[_lib.STAT_NUM_GLOBAL] > 0:
+                scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=X.device)
+            gkey = torch.zeros((max(nnz, 1), S), dtype=torch.float32, device=X.device)
+            gf = torch.zeros(S, dtype=torch.float32, device=X.device)
+            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch)
+            _lib.check(L.fsw_embed_backward_keys_f32(ctypes.byref(a), _lib.ptr(g), g.stride(0), _lib.ptr(gkey), S, _lib.ptr(gf), stream),
+                       "fsw_embed_backward_keys_f32")
+            gkey, ef, Vd = gkey[:nnz], graph.ef[:nnz], V.detach()
+            if need_xp:
+                gXp = torch.zeros((X.shape[0], S), dtype=torch.float32, device=X.device).index_add_(0, graph.col[:nnz].long(), gkey)
+                if ctx.needs_input_grad[0]:
+                    gX = gXp @ Vd[:, :module.d_in]
+                if ctx.needs_input_grad[1]:
+                    gV = torch.cat([gXp.t() @ X.detach(), gkey.t() @ ef], dim=1)
+            if ctx.needs_input_grad[2]:
+                gfreqs = gf
+            if ctx.needs_input_grad[5]:
+                slot = graph.slot_of_edge[:edge_feat_rows(ctx)].long()
+                gslots = gkey @ Vd[:, module.d_in:]
+                gEf = torch.where((slot >= 0)[:, None], gslots[slot.clamp(min=0)], torch.zeros((), device=X.device))
+        elif need_xp or ctx.needs_input_grad[2]:
             gXp = torch.zeros((X.shape[0], ldp), dtype=torch.float32, device=X.device)
             fr = freqs.detach()
             dtable = None
@@ -87,7 +118,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
                                                 _lib.ptr(gf), stream), "fsw_embed_backward_f32")
             if ctx.needs_input_grad[0]:
-                gX = gXp[:, :S] @ V.detach()
+                gX = gXp[:, :S] @ V.detach()[:, :module.d_in]
             if ctx.needs_input_grad[1]:
                 gV = gXp[:, :S].t() @ X.detach()
             if ctx.needs_input_grad[2]:
@@ -104,7 +135,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             fn = module.total_mass_encoding_function
             fm = m if fn == 'identity' else (2 * (m / (torch.sqrt(m + 1) + 1)) if fn == 'sqrt' else torch.log1p(m))
             gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())
-        return gX, gV, gfreqs, gbias, gscale, None, None, None
+        return gX, gV, gfreqs, gbias, gscale, gEf, None, None, None
 
 
 class FSW_embedding(nn.Module):
@@ -166,9 +197,6 @@ class FSW_embedding(nn.Module):
         else:
             assert False, "Expected exactly one of (d_out != None) or (nSlices != None and nFreqs != None)"
         assert self.d_out >= 0, 'd_out must be nonnegative'
-        if d_edge > 0:
-            raise NotImplementedError("fsw_gnn_amd: edge features (d_edge > 0) are not implemented yet (SURVEY.md 8f #2)")
-
         self.minimize_slice_coherence = minimize_slice_coherence
         self.learnable_slices = learnable_slices
         self.learnable_freqs = learnable_freqs
@@ -307,7 +335,16 @@ class FSW_embedding(nn.Module):
         coalesced torch.sparse_coo, X shared by the recipients.  Returns (<batch>, [nRecipients,] d_out).
         """
         assert self.total_mass_pad_thresh > 0, 'total_mass_pad_thresh must be positive'
-        assert (X_edge is None) or (X_edge.numel() == 0), 'X_edge should be None or empty since d_edge == 0'
+        if self.d_edge > 0:
+            assert graph_mode, 'd_edge > 0 (given at initialization) necessitates graph_mode=True on forward call'
+            assert X_edge is not None, 'X_edge must be provided since d_edge > 0'
+            assert torch.is_tensor(W), 'When X_edge is provided, W must be provided explicitly'
+            assert X_edge.device == self.get_device() and X_edge.dtype == self.get_dtype(), 'X_edge has the wrong device or dtype'
+            assert X_edge.is_sparse == W.is_sparse, 'X_edge and W must either both or neither be sparse'
+            if torch.is_grad_enabled() and X_edge.requires_grad:
+                raise NotImplementedError("fsw_gnn_amd: gradients w.r.t. X_edge are provided through FSW_conv(edge_features=...) only")
+        else:
+            assert (X_edge is None) or (X_edge.numel() == 0), 'X_edge should be None or empty since d_edge == 0'
         assert torch.is_tensor(X), 'X must be a pytorch tensor. Instead got type %s' % (type(X))
         assert torch.is_tensor(W) or W in {'unit', 'uniform'}, "W must be a pytorch tensor, 'unit' or 'uniform'"
         assert X.dtype == self.get_dtype(), ("X has the wrong dtype. Expected %s, got %s" % (self.get_dtype(), X.dtype))
@@ -353,11 +390,22 @@ class FSW_embedding(nn.Module):
             assert (len(W.shape) == len(X.shape)) and (W.shape[-1] == X.shape[-2]) and (tuple(W.shape[0:-2]) == tuple(X.shape[0:-2])), \
                 "Shape mismatch between X and W: When graph_mode=True, if W.shape = (b1,b2,...,bk,nRecipients,n) then X.shape should be (b1,b2,...,bk,n,d_in)"
             B = int(np.prod(batch_dims)) if batch_dims else 1
+            efvals = None
             if W.is_sparse:
                 idx, wvals = W.indices(), W.values()
+                if self.d_edge > 0:
+                    assert X_edge.is_coalesced() and X_edge.values().shape[0] == wvals.shape[0], \
+                        'Sparse X_edge must have the same number of values() as W'
+                    if fsw_embedding_basic_safety_checks:
+                        assert (X_edge.indices() == idx).all(), 'Sparse X_edge must have the same nonzero pattern as W'
+                    efvals = X_edge.values().reshape(wvals.shape[0], -1)
             else:
                 idx = W.nonzero(as_tuple=False).t().contiguous()
                 wvals = W[tuple(idx)]
+                if self.d_edge > 0:
+                    efvals = X_edge[tuple(idx)].reshape(wvals.shape[0], -1)
+            if self.d_edge > 0:
+                assert efvals.shape[1] == self.d_edge, 'X_edge must carry d_edge features per edge'
             if batch_dims:
                 strides = torch.tensor(list(np.cumprod((batch_dims + (1,))[::-1])[::-1][1:]), device=X.device, dtype=torch.int64)
                 b = (idx[:len(batch_dims)] * strides[:, None]).sum(0)
@@ -368,7 +416,10 @@ class FSW_embedding(nn.Module):
             Xf = X.reshape(B * n, d)
             num_rows, out_shape = B * nR, batch_dims + (nR,)
 
-        graph = build_csr(rec, snd, wvals, num_rows, Xf.shape[0])
+        if self.d_edge > 0:
+            graph = build_csr_coalesced(rec, snd, wvals.contiguous(), efvals.contiguous(), num_rows, Xf.shape[0])
+        else:
+            graph = build_csr(rec, snd, wvals, num_rows, Xf.shape[0])
         if needs_grad:
             out = self.embed_autograd(Xf.contiguous(), graph)
         else:
@@ -376,13 +427,16 @@ class FSW_embedding(nn.Module):
             self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
         return out.reshape(out_shape + (self.d_out,))
 
-    def embed_autograd(self, X, graph, out_scale=1.0):
-        """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn."""
+    def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None):
+        """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn.  edge_feat: the per-input-edge
+        feature tensor the graph was coalesced from (its gradient is routed back through graph.slot_of_edge)."""
         bias = self.bias if self.enable_bias else None
         scale = self.total_mass_encoding_scale if self.encode_total_mass else None
-        return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, self, graph, out_scale)
+        return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale)
 
     # ------------------------------------------------------------------------------------------------
+    _slice_offset = 0   # first slice of the block being processed (slice sharding / serialize_num_slices)
+
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):
         """Projection of all slices + (unit weights) coefficient table + the one device->host stats read.
 
@@ -448,6 +502,10 @@ class FSW_embedding(nn.Module):
         a.max_degree = st[_lib.STAT_MAX_DEGREE]
         a.scratch = scratch.data_ptr() if scratch is not None else None
         a.scratch_bytes = scratch.numel() if scratch is not None else 0
+        if graph.ef is not None:            # edge features: Ve = projVecs[:, d_in:], read in place (row stride d_in + d_edge)
+            V = self.projVecs.detach()
+            a.efeat, a.d_edge = graph.ef.data_ptr(), self.d_edge
+            a.Ve, a.ldve = V.data_ptr() + 4 * (self._slice_offset * V.stride(0) + self.d_in), V.stride(0)
         return a
 
     def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None, prepared=None):
@@ -499,10 +557,12 @@ class FSW_embedding(nn.Module):
         V = self.projVecs.detach()[ka:kb]
         freqs = self.freqs.detach()[ka:kb]
         scratch = None
+        assert (graph.ef is None) == (self.d_edge == 0), 'edge features must be given exactly when d_edge > 0'
         for k0 in range(0, S, step):
             k1 = min(S, k0 + step)
             Sc = k1 - k0
             fc = freqs[k0:k1]
+            self._slice_offset = ka + k0
             if prepared is None:
                 Vc = V[k0:k1]
                 rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
@@ -524,6 +584,7 @@ class FSW_embedding(nn.Module):
                                (bias.data_ptr() + 4 * col0) if bias is not None else None, out_scale, hm, scratch)
             rc = L.fsw_embed_f32(ctypes.byref(a), stream)
             _lib.check(rc, "fsw_embed_f32")
+        self._slice_offset = 0
 
         if not plain:
             # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): rarely used epilogues, done with

@@ -17,11 +17,14 @@ class CSRGraph:
     stats_dev int32[NUM_STATS] (device) -- read back once per forward by `stats()`.
     """
 
-    def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None):
+    def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None, ef=None,
+                 slot_of_edge=None):
         self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
         self.rowptr, self.col, self.w, self.perm, self.bin_start = rowptr, col, w, perm, bin_start
         self.stats_dev = stats_dev
         self.invperm = invperm
+        self.ef = ef                        # [num_edges, d_edge] summed edge features of the coalesced entries, or None
+        self.slot_of_edge = slot_of_edge    # int32[num_input_edges]: CSR entry of every input edge (coalesced build)
         self._stats = None
 
     def stats(self):
@@ -72,3 +75,42 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
                            _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
     return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, invperm)
+
+
+def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_cols, want_slots=False):
+    """Coalescing build: entries sorted by (recipient, sender), parallel edges merged (weights and edge features summed),
+    like torch.sparse_coo_tensor(...).coalesce() in the reference (fsw_conv.py:397-398, 436-437).  Used with edge features.
+
+    edge_w float32 [E] or None (1 per edge); edge_feat float32 [E, d_edge] or None.  The CSR arrays are sized for E
+    entries, the first graph.stats()[STAT_NNZ] are valid."""
+    L = _lib.lib()
+    dev = recipients.device
+    if dev.type != "cuda":
+        raise RuntimeError("fsw_gnn_amd.build_csr_coalesced: tensors must live on a HIP device (no CPU path)")
+    assert recipients.dtype == torch.int64 and senders.dtype == torch.int64 and recipients.shape == senders.shape
+    recipients, senders = recipients.contiguous(), senders.contiguous()
+    E = recipients.numel()
+    d_edge = 0
+    if edge_feat is not None:
+        assert edge_feat.dtype == torch.float32 and edge_feat.dim() == 2 and edge_feat.shape[0] == E
+        edge_feat = edge_feat.contiguous()
+        d_edge = edge_feat.shape[1]
+    if edge_w is not None:
+        assert edge_w.dtype == torch.float32 and edge_w.shape == recipients.shape
+        edge_w = edge_w.contiguous()
+    rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    w = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    ef = torch.empty((max(E, 1), d_edge), dtype=torch.float32, device=dev) if d_edge else None
+    slot = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_slots else None
+    perm = torch.empty(num_rows, dtype=torch.int32, device=dev)
+    bin_start = torch.empty(_lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
+    stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
+    ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.fsw_graph_build_coalesced(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), _lib.ptr(edge_feat), d_edge, E,
+                                     num_rows, num_cols, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(ef), _lib.ptr(slot),
+                                     _lib.ptr(perm), None, _lib.ptr(bin_start), _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
+    _lib.check(rc, "fsw_graph_build_coalesced")
+    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, None, ef, slot)

@@ -53,7 +53,7 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
 #define FSW_STAT_NUM_REG 3      /* rows with 1 <= degree <= FSW_REG_MAX_DEG */
 #define FSW_STAT_NUM_LDS 4
 #define FSW_STAT_NUM_GLOBAL 5
-#define FSW_STAT_GLOBAL_PAD_ELEMS 6 /* sum over global-path rows of pow2ceil(degree + 1), saturating */
+#define FSW_STAT_NNZ 6          /* fsw_graph_build_coalesced: number of CSR entries after coalescing */
 #define FSW_NUM_STATS 8
 
 #define FSW_FLAG_INDEX_RANGE 1   /* an edge endpoint outside [0, num_rows) x [0, num_cols) */
@@ -82,6 +82,19 @@ int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const flo
                     int64_t num_edges, int64_t num_rows, int64_t num_cols,
                     int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* invperm, int32_t* bin_start,
                     int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
+
+/* Coalescing variant: entries sorted by (recipient, sender), parallel edges merged into ONE entry whose
+ * weight (edge_w or 1 per edge) and edge-feature vector are the sums over the duplicates -- exactly what
+ * torch.sparse_coo_tensor(...).coalesce() does to adj and X_edge in the reference (fsw_conv.py:397-398,
+ * 436-437).  Required with edge features (the key of an element then depends on its feature vector, so
+ * parallel edges are no longer equivalent to separate elements).  col/w/ef are sized for num_edges
+ * entries, the first stats[FSW_STAT_NNZ] are used.  slot_of_edge int32[num_edges] (nullable): CSR
+ * position of every input edge (-1 for rejected edges) -- the backward routes feature gradients with it. */
+int fsw_graph_build_coalesced(const int64_t* recipients, const int64_t* senders, const float* edge_w,
+                              const float* edge_feat, int d_edge, int64_t num_edges, int64_t num_rows, int64_t num_cols,
+                              int32_t* rowptr, int32_t* col, float* w, float* ef, int32_t* slot_of_edge, int32_t* perm,
+                              int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace, size_t workspace_bytes,
+                              fsw_stream_t stream);
 
 /* ---- projection: Xp[n, ldp] = X[n, ldx] . V[S, ldv]^T, fp32 MFMA (v_mfma_f32_32x32x2_f32) -------
  * Replaces torch.tensordot(X, projVecs) (reference fsw_embedding.py:909-913).  Sets
@@ -134,6 +147,14 @@ typedef struct {
   /* scratch for the global path: >= fsw_embed_scratch_bytes() or NULL if num_global_rows == 0 */
   void* scratch;
   size_t scratch_bytes;
+  /* edge features (reference fsw_embedding.py:934-968): the key of CSR entry e of slice k is
+   * Xp[col[e], k] + sum_q efeat[e*d_edge + q] * Ve[k*ldve + q]   (Ve = projVecs[:, d_in:]).  Needs w != NULL
+   * (a graph from fsw_graph_build_coalesced).  efeat == NULL / d_edge == 0: no edge features.          */
+  const float* efeat;
+  const float* Ve;
+  int64_t ldve;
+  int32_t d_edge;
+  int32_t reserved;
 } fsw_embed_args;
 
 size_t fsw_embed_scratch_bytes(int64_t max_degree);
@@ -178,6 +199,11 @@ int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw,
 int fsw_unit_dcoeff_table(const float* freqs, int S, int max_deg, float* dtable, int64_t ldt, fsw_stream_t stream);
 int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gXp,
                            int64_t ldgp, float* gfreq, fsw_stream_t stream);
+/* Edge-feature graphs: the same backward, but the gradient of every KEY is stored instead of being accumulated:
+ * gkey[e*ldk + k] = out_scale * g[i,k] * C(entry e, slice k) for CSR entry e of row i (gkey zeroed by the caller).
+ * From it: gXp = scatter-add of gkey rows by col, g_efeat = gkey . Ve, gVe = gkey^T . efeat.               */
+int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int64_t ldg, float* gkey, int64_t ldk,
+                                float* gfreq, fsw_stream_t stream);
 
 /* ---- stand-alone segmented cumulative sum --------------------------------------------------------
  * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of

@@ -17,7 +17,7 @@ import numpy as np
 # adjacency construction                                                     fsw_conv.py:384-447
 # --------------------------------------------------------------------------------------------------
 def coalesce_edge_index(edge_index, num_vertices, self_loop_weight=0.0, edge_weighting="unit",
-                        edge_values=None, dtype=np.float64):
+                        edge_values=None, dtype=np.float64, edge_features=None):
     """edge_index [2,E] (row 0 = sender, row 1 = recipient) -> CSR of adj[recipient, sender].
 
     fsw_conv.py:387      inds = edge_index.flip(0)  (row = recipient, col = sender)
@@ -25,17 +25,24 @@ def coalesce_edge_index(edge_index, num_vertices, self_loop_weight=0.0, edge_wei
     fsw_conv.py:390-395  optional self loops of weight self_loop_weight
     fsw_conv.py:397-398  coalesce(): duplicates summed, entries sorted by (recipient, sender)
     fsw_conv.py:400-409  in-degrees; 'gcn' weighting divides by sqrt(deg_i) * sqrt(deg_j)
+    fsw_conv.py:419-439  edge features: same indices, coalesce() sums the feature vectors of duplicate edges; self
+                         loops carry zero features.  With edge_features the return value gains ef[nnz, d_edge] and
+                         slot[E] (CSR position of every input edge).
     Returns rowptr[int64 n+1], col[int64 nnz], w[dtype nnz], in_degrees[dtype n].
     """
     edge_index = np.asarray(edge_index)
     src = edge_index[0].astype(np.int64)
     dst = edge_index[1].astype(np.int64)
     vals = np.ones(src.shape[0], dtype=dtype) if edge_values is None else np.asarray(edge_values, dtype=dtype)
+    ef_in = None if edge_features is None else np.asarray(edge_features, dtype=dtype).reshape(src.shape[0], -1)
+    num_input_edges = src.shape[0]
     if self_loop_weight > 0:
         loops = np.arange(num_vertices, dtype=np.int64)
         src = np.concatenate([src, loops])
         dst = np.concatenate([dst, loops])
         vals = np.concatenate([vals, np.full(num_vertices, self_loop_weight, dtype=dtype)])
+        if ef_in is not None:
+            ef_in = np.concatenate([ef_in, np.zeros((num_vertices, ef_in.shape[1]), dtype=dtype)])
     key = dst * np.int64(num_vertices) + src
     order = np.argsort(key, kind="stable")
     key = key[order]
@@ -60,6 +67,12 @@ def coalesce_edge_index(edge_index, num_vertices, self_loop_weight=0.0, edge_wei
         w = w / ds[row] / ds[col]
     elif edge_weighting != "unit":
         raise RuntimeError("Invalid weighting method passed in argument <edge_weighting>")
+    if ef_in is not None:
+        ef = np.zeros((ukey.shape[0], ef_in.shape[1]), dtype=dtype)
+        np.add.at(ef, seg, ef_in[order])
+        slot = np.empty(order.shape[0], dtype=np.int64)
+        slot[order] = seg
+        return rowptr, col, w, in_deg, ef, slot[:num_input_edges]
     return rowptr, col, w, in_deg
 
 
@@ -75,7 +88,7 @@ def csr_from_coo(rows, cols, vals, num_rows):
 # embedding core                                                       fsw_embedding.py:778-1112
 # --------------------------------------------------------------------------------------------------
 def fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh=1.0, dtype=np.float64,
-                  chunk_elems=1 << 23, return_mass=False):
+                  chunk_elems=1 << 23, return_mass=False, edge_feat=None):
     """out[r, k] = (1+xi_k) * sum_t Delta_t * p_(t)  for every CSR row r and slice k.
 
     fsw_embedding.py:778-784    mass m_r = sum of the row's weights
@@ -89,9 +102,16 @@ def fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh=1.0,
     fsw_embedding.py:1047-1075  Delta_t = 2 w_t sinc(xi w_t) cos(pi xi (2 c_t - w_t)),
                                 sinc(z) = sin(pi z)/(pi z)
     fsw_embedding.py:1084-1109  out = (1+xi) * sum_t Delta_t p_(t)
+    fsw_embedding.py:934-968    edge features (edge_feat [nnz, d_edge], projVecs [S, d_in + d_edge]): the key of
+                                neighbour j of recipient i is <x_j, v[:d_in]> + <e_ij, v[d_in:]>; the pad element stays 0
     """
     X = np.asarray(X, dtype=dtype)
     V = np.asarray(projVecs, dtype=dtype)
+    Ve = None
+    if edge_feat is not None:
+        edge_feat = np.asarray(edge_feat, dtype=dtype)
+        Ve = V[:, X.shape[1]:]
+        V = V[:, :X.shape[1]]
     xi = np.asarray(freqs, dtype=dtype)
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
@@ -124,6 +144,8 @@ def fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh=1.0,
             wts = np.zeros((R, Dp), dtype=dtype)
             if D > 0:
                 keys[:, :D, :] = Xp[col[idx]]
+                if Ve is not None:
+                    keys[:, :D, :] += edge_feat[idx] @ Ve.T
                 wts[:, :D] = w[idx]
             if any_deficit:
                 wts[:, D] = deficit[rr]                            # pad element at x = 0
@@ -170,9 +192,10 @@ def total_mass_encode(out, mass, function="identity", method="plain", scale=1.0)
 
 def fsw_embedding_forward(X, rowptr, col, w, projVecs, freqs, bias=None, encode_total_mass=False,
                           total_mass_encoding_function="identity", total_mass_encoding_method="plain",
-                          total_mass_encoding_scale=1.0, total_mass_pad_thresh=1.0, dtype=np.float64):
+                          total_mass_encoding_scale=1.0, total_mass_pad_thresh=1.0, dtype=np.float64, edge_feat=None):
     """FSW_embedding.forward in graph mode on a CSR adjacency.    fsw_embedding.py:587-890"""
-    emb, mass = fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh, dtype, return_mass=True)
+    emb, mass = fsw_embed_csr(X, rowptr, col, w, projVecs, freqs, total_mass_pad_thresh, dtype, return_mass=True,
+                              edge_feat=edge_feat)
     if encode_total_mass:
         emb = total_mass_encode(emb, mass, total_mass_encoding_function, total_mass_encoding_method,
                                 np.dtype(dtype).type(total_mass_encoding_scale))
@@ -241,7 +264,7 @@ def _dsinc(z):
 
 
 def fsw_embed_csr_backward(X, rowptr, col, w, projVecs, freqs, G, total_mass_pad_thresh=1.0, chunk_elems=1 << 22,
-                           return_gXp=False, Xp_override=None):
+                           return_gXp=False, Xp_override=None, edge_feat=None, keys_override=None):
     """Gradients of sum(out * G) for out = fsw_embed_csr(...) with respect to X, projVecs and freqs (float64).
 
     The reference obtains them by reverse-mode autograd through its sparse ops: sum_sparseToDense.backward,
@@ -258,6 +281,11 @@ def fsw_embed_csr_backward(X, rowptr, col, w, projVecs, freqs, G, total_mass_pad
     """
     X = np.asarray(X, dtype=np.float64)
     V = np.asarray(projVecs, dtype=np.float64)
+    Ve = gkey_all = None
+    if edge_feat is not None:      # edge features: returns (gX, gV [S, d_in + d_edge], gxi, g_edge_feat [nnz, d_edge])
+        edge_feat = np.asarray(edge_feat, dtype=np.float64)
+        Ve, V = V[:, X.shape[1]:], V[:, :X.shape[1]]
+        gkey_all = np.zeros((edge_feat.shape[0], V.shape[0]))
     xi = np.asarray(freqs, dtype=np.float64)
     G = np.asarray(G, dtype=np.float64)
     rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -288,6 +316,10 @@ def fsw_embed_csr_backward(X, rowptr, col, w, projVecs, freqs, G, total_mass_pad
             keys = np.zeros((R, Dp, S))
             wts = np.zeros((R, Dp))
             keys[:, :D, :] = Xp[col[idx]]
+            if Ve is not None:
+                keys[:, :D, :] += edge_feat[idx] @ Ve.T
+            if keys_override is not None:                                       # float32 keys of the path under test
+                keys[:, :D, :] = np.asarray(keys_override, dtype=np.float64)[idx]
             wts[:, :D] = w[idx]
             if any_deficit:
                 wts[:, D] = deficit[rr]
@@ -307,6 +339,10 @@ def fsw_embed_csr_backward(X, rowptr, col, w, projVecs, freqs, G, total_mass_pad
             gk = np.zeros_like(gk_sorted)
             np.put_along_axis(gk, order, gk_sorted, axis=1)                    # back to neighbour order
             np.add.at(gXp, col[idx], gk[:, :D, :])                             # the pad element has no source row
+            if gkey_all is not None:
+                gkey_all[idx] = gk[:, :D, :]
+    if gkey_all is not None:
+        return gXp @ V, np.concatenate([gXp.T @ X, gkey_all.T @ edge_feat], axis=1), gxi, gkey_all @ Ve
     if return_gXp:
         return gXp @ V, gXp.T @ X, gxi, gXp
     return gXp @ V, gXp.T @ X, gxi

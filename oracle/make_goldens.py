@@ -234,6 +234,40 @@ def case_grads(emb, conv):
          gb=C.mlp[0].bias.grad.numpy())
 
 
+def case_edgefeat(emb, conv):
+    """Edge features (reference fsw_embedding.py:934-968, fsw_conv.py:419-439): FSW_conv with edgefeat_dim = 3 on
+    the tiny multigraph (duplicate edges: the reference sums their features and weights in coalesce()), forward and
+    autograd gradients in float64; plus a self-loop variant (loops carry zero edge features, fsw_conv.py:428-433)."""
+    g = np.load(os.path.join(GOLD, "tiny_graph.npz"))
+    dt = torch.float64
+    n, d, de, out_ch, embed_dim = 64, 8, 3, 5, 17
+    ei, X0 = g["edge_index"], g["X"]
+    EF = synth.normal(95, 1, (ei.shape[1], de), dtype=np.float64)
+    V = synth.unit_slices(embed_dim - 1, d + de, seed=96)
+    fr = cases.random_freqs(embed_dim - 1, seed=97)
+    Wl = (synth.normal(98, 1, (out_ch, embed_dim + d), dtype=np.float64) / 5).astype(np.float32)
+    bl = (0.1 * synth.normal(99, 1, (out_ch,), dtype=np.float64)).astype(np.float32)
+    R = synth.normal(94, 1, (n, out_ch), dtype=np.float64)
+    arrays = dict(edge_features=EF, V=V, freqs=fr, lin_w=Wl, lin_b=bl, R=R)
+    for tag, kw in (("plain", {}), ("selfloop", {"self_loop_weight": 0.5})):
+        C = conv.FSW_conv(d, out_ch, edgefeat_dim=de, embed_dim=embed_dim, device="cpu", dtype=dt, **kw)
+        set_params(C.fsw_embed, V, fr)
+        with torch.no_grad():
+            C.mlp[0].weight.copy_(T(Wl, dt))
+            C.mlp[0].bias.copy_(T(bl, dt))
+        X = T(X0, dt).requires_grad_(True)
+        Ef = torch.from_numpy(EF).requires_grad_(True)
+        y = C(X, torch.from_numpy(ei), edge_features=Ef)
+        (y * torch.from_numpy(R)).sum().backward()
+        adj, X_edge, _ = conv.FSW_conv.edge_index_to_adj(torch.from_numpy(ei), Ef.detach(), n, de, dt, **kw)
+        with torch.no_grad():
+            e = C.fsw_embed(X.detach(), adj, X_edge, graph_mode=True)
+        arrays.update({"y_" + tag: y.detach().numpy(), "emb_" + tag: e.numpy(), "gX_" + tag: X.grad.numpy(),
+                       "gEF_" + tag: Ef.grad.numpy(), "gV_" + tag: C.fsw_embed.projVecs.grad.numpy(),
+                       "gfreqs_" + tag: C.fsw_embed.freqs.grad.numpy(), "gW_" + tag: C.mlp[0].weight.grad.numpy()})
+    save("edgefeat_tiny", **arrays)
+
+
 def case_coherence(emb):
     """minimize_mutual_coherence (fsw_embedding.py:3045-3248) on three fixed starting points, float64."""
     out = {}
@@ -293,10 +327,12 @@ def main():
         case_grads(emb, conv)
     elif what == "coherence":
         case_coherence(emb)
+    elif what == "edgefeat":
+        case_edgefeat(emb, conv)
     elif what == "er1m":
         timings.update(case_er1m(emb, conv))
     else:
-        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|coherence|er1m]")
+        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|coherence|edgefeat|er1m]")
     json.dump(timings, open(timings_path, "w"), indent=1, sort_keys=True)
 
 

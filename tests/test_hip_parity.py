@@ -35,7 +35,8 @@ def make_embedding(dev, V, freqs, bias=None, scale=None, **kw):
     encode = kw.get("encode_total_mass", False)
     E = FSW_embedding(d_in=d, d_out=S + (1 if encode else 0), device=dev, **kw)
     with torch.no_grad():
-        E.projVecs.copy_(t(V, dev))
+        if E.d_edge == 0:
+            E.projVecs.copy_(t(V, dev))
         E.freqs.copy_(t(freqs, dev))
         if bias is not None and E.enable_bias:
             E.bias.copy_(t(bias, dev))
@@ -514,3 +515,69 @@ def test_fused_conv_odd_shapes_match_unfused_and_oracle(dev, n, E, d, out_ch, em
     with torch.no_grad():
         ref = conv.mlp.double().cpu()(h).numpy()
     assert relerr(y_f, ref) < TOL
+
+
+@pytest.mark.parametrize("tag,slw", [("plain", 0.0), ("selfloop", 0.5)])
+def test_edge_features_conv_forward_and_backward(dev, tag, slw):
+    """FSW_conv with edgefeat_dim = 3 on the tiny multigraph (duplicate edges are coalesced: features and weights summed)
+    against the reference's forward and autograd (float64 goldens)."""
+    from fsw_gnn_amd import FSW_conv
+    g, ge = golden("tiny_graph"), golden("edgefeat_tiny")
+    d, de, out_ch, embed_dim = 8, 3, 5, 17
+    conv = FSW_conv(d, out_ch, edgefeat_dim=de, embed_dim=embed_dim, self_loop_weight=slw, device=dev)
+    with torch.no_grad():
+        conv.fsw_embed.projVecs.copy_(t(ge["V"], dev))
+        conv.fsw_embed.freqs.copy_(t(ge["freqs"], dev))
+        conv.mlp[0].weight.copy_(t(ge["lin_w"], dev))
+        conv.mlp[0].bias.copy_(t(ge["lin_b"], dev))
+    ei = t(g["edge_index"], dev, torch.int64)
+    with torch.no_grad():
+        y = conv(t(g["X"], dev), ei, edge_features=t(ge["edge_features"], dev))
+        graph = conv.build_graph(ei, 64, t(ge["edge_features"], dev))
+        emb = torch.empty((64, embed_dim), device=dev)
+        conv.fsw_embed.embed_into(t(g["X"], dev), graph, emb)
+    assert relerr(emb.cpu().numpy(), ge["emb_" + tag]) < TOL
+    assert relerr(y.cpu().numpy(), ge["y_" + tag]) < TOL
+    # coalesced adjacency == the oracle's (and the reference's) sorted, merged entries
+    rowptr, col, w, _, ef, slot = O.coalesce_edge_index(g["edge_index"], 64, self_loop_weight=slw, edge_features=ge["edge_features"])
+    nnz = graph.stats()[6]
+    assert nnz == col.shape[0] and np.array_equal(graph.rowptr.cpu().numpy(), rowptr) and np.array_equal(graph.col[:nnz].cpu().numpy(), col)
+    assert relerr(graph.w[:nnz].cpu().numpy(), w) < 1e-7 and relerr(graph.ef[:nnz].cpu().numpy(), ef) < 1e-6
+    assert np.array_equal(graph.slot_of_edge[:400].cpu().numpy(), slot)
+    # training step: gradients for vertex features, edge features, slices (vertex and edge part), frequencies, MLP
+    X = t(g["X"], dev).requires_grad_(True)
+    EF = t(ge["edge_features"], dev).requires_grad_(True)
+    y2 = conv(X, ei, edge_features=EF)
+    (y2 * t(ge["R"], dev)).sum().backward()
+    assert relerr(X.grad.cpu().numpy(), ge["gX_" + tag]) < 3e-5
+    assert relerr(EF.grad.cpu().numpy(), ge["gEF_" + tag]) < 3e-5
+    assert relerr(conv.fsw_embed.projVecs.grad.cpu().numpy(), ge["gV_" + tag]) < 3e-5
+    assert relerr(conv.fsw_embed.freqs.grad.cpu().numpy(), ge["gfreqs_" + tag]) < 3e-5
+    assert relerr(conv.mlp[0].weight.grad.cpu().numpy(), ge["gW_" + tag]) < 3e-5
+
+
+def test_edge_features_embedding_sparse_inputs_and_long_rows(dev):
+    """FSW_embedding(d_edge > 0).forward(X, W sparse, X_edge sparse) incl. one row of 300 neighbours (LDS path)."""
+    rng = np.random.default_rng(5)
+    n, d, de, S = 400, 6, 2, 12
+    src = np.concatenate([rng.integers(0, n, 1500), np.arange(300)])
+    dst = np.concatenate([rng.integers(1, n, 1500), np.zeros(300, dtype=np.int64)])
+    key = np.unique(dst * n + src)
+    dst, src = key // n, key % n
+    wv = (rng.random(key.shape[0]) + 0.2).astype(np.float32)
+    ef = rng.standard_normal((key.shape[0], de)).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d + de, seed=85)
+    fr = cases.random_freqs(S, seed=86)
+    E = make_embedding(dev, V[:, :d], fr, enable_bias=False, d_edge=de)
+    with torch.no_grad():
+        E.projVecs.copy_(t(V, dev))
+        idx = torch.from_numpy(np.stack([dst, src])).to(dev)
+        W = torch.sparse_coo_tensor(idx, t(wv, dev), (n, n)).coalesce()
+        Xe = torch.sparse_coo_tensor(idx, t(ef, dev), (n, n, de)).coalesce()
+        out = E(t(X, dev), W, Xe, graph_mode=True).cpu().numpy()
+        out_d = E(t(X, dev), W.to_dense(), Xe.to_dense(), graph_mode=True).cpu().numpy()      # dense W / X_edge
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))])
+    ref = O.fsw_embedding_forward(X, rowptr, src, wv, V, fr, edge_feat=ef)
+    assert np.diff(rowptr).max() >= 300
+    assert relerr(out, ref) < TOL and relerr(out_d, ref) < TOL

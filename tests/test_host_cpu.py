@@ -54,7 +54,7 @@ def test_embed_args_struct_matches_header_layout():
         names.append(re.findall(r"[A-Za-z_0-9]+", first)[-1])
         names += [re.findall(r"[A-Za-z_0-9]+", r)[-1] for r in rest]
     assert names == [f[0] for f in _lib.EmbedArgs._fields_]
-    assert ctypes.sizeof(_lib.EmbedArgs) == 8 * 6 + 8 * 3 + 8 + 8 * 2 + 8 * 3 + 16 + 8 * 5 + 16
+    assert ctypes.sizeof(_lib.EmbedArgs) == 8 * 6 + 8 * 3 + 8 + 8 * 2 + 8 * 3 + 16 + 8 * 5 + 16 + 8 * 3 + 8
 
 
 def test_sorting_networks_native():
@@ -92,8 +92,8 @@ def test_module_surface_and_loud_failures():
         FSW_conv(6, 10, device="cpu", config={"no_such_option": 1})
     C2 = FSW_conv(6, 10, device="cpu", config={"mlp_layers": 0, "concat_self": False})
     assert C2.embed_dim == 10 and C2.mlp is None and C2.fsw_embed.enable_bias
-    with pytest.raises(NotImplementedError):
-        FSW_conv(6, 10, edgefeat_dim=3, device="cpu")
+    C3 = FSW_conv(6, 10, edgefeat_dim=3, device="cpu")                    # projVecs cover vertex + edge features
+    assert tuple(C3.fsw_embed.projVecs.shape) == (19, 9) and C3.fsw_embed.d_edge == 3 and not C3._fusable()
 
 
 def test_slice_partition():

@@ -163,3 +163,24 @@ def test_backward_oracle_conv10k():
     assert relerr(gX[gg["rows"]], gg["gX_rows"]) < 1e-9
     assert relerr(gV, gg["gV"]) < 1e-9 and relerr(gxi, gg["gfreqs"]) < 1e-9
     assert relerr(gpre.T @ h, gg["gW"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag,slw", [("plain", 0.0), ("selfloop", 0.5)])
+def test_edge_features_oracle_forward_and_backward(tag, slw):
+    """Edge features (reference fsw_embedding.py:934-968, fsw_conv.py:419-439) incl. duplicate edges and self loops."""
+    g, ge = golden("tiny_graph"), golden("edgefeat_tiny")
+    n, d, de = 64, 8, 3
+    rowptr, col, w, _, ef, slot = O.coalesce_edge_index(g["edge_index"], n, self_loop_weight=slw, edge_features=ge["edge_features"])
+    X = g["X"].astype(np.float64)
+    emb = O.fsw_embedding_forward(X, rowptr, col, w, ge["V"], ge["freqs"], encode_total_mass=True, edge_feat=ef)
+    assert relerr(emb, ge["emb_" + tag]) < TOL64
+    Wl, bl = ge["lin_w"].astype(np.float64), ge["lin_b"].astype(np.float64)
+    pre = np.concatenate([emb, X], axis=1) @ Wl.T + bl
+    assert relerr(np.where(pre >= 0, pre, 0.2 * pre), ge["y_" + tag]) < TOL64
+    gpre = ge["R"] * np.where(pre >= 0, 1.0, 0.2)
+    gh = gpre @ Wl
+    E = emb.shape[1]
+    gX, gV, gxi, gef = O.fsw_embed_csr_backward(X, rowptr, col, w, ge["V"], ge["freqs"], gh[:, 1:E], edge_feat=ef)
+    assert relerr(gX + gh[:, E:], ge["gX_" + tag]) < 1e-10
+    assert relerr(gV, ge["gV_" + tag]) < 1e-10 and relerr(gxi, ge["gfreqs_" + tag]) < 1e-10
+    assert relerr(gef[slot], ge["gEF_" + tag]) < 1e-10                       # every duplicate receives its slot's gradient
