@@ -171,10 +171,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL ("nccl") over xGMI, one rank per GPU.  FSW_BENCH_BACKEND=gloo is a functional rehearsal on a box with
+        # fewer GPUs than ranks (ranks then share a device; numbers from it mean nothing).
+        backend = os.environ.get("FSW_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fsw_gnn_amd import FSW_conv
     n, E = args.nodes, args.edges
