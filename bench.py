@@ -142,6 +142,35 @@ def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
     return roof, ms
 
 
+def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
+    """N > 1: the dominant kernel of a rank is k_embed_reg_unit on its own block of slices (unfused kernels + all-gather)."""
+    from fsw_gnn_amd import _lib
+    from fsw_gnn_amd.dist import slice_partition
+    L = _lib.lib()
+    emb = conv.fsw_embed
+    ka, kb = slice_partition(emb.nSlices, world)[rank]
+    Sl = kb - ka
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    graph = conv.build_graph(ei, n)
+    st = graph.stats()
+    ldp = (Sl + 63) // 64 * 64
+    Xp = torch.empty((n, ldp), dtype=torch.float32, device=dev)
+    V, fr = emb.projVecs.detach()[ka:kb], emb.freqs.detach()[ka:kb]
+    table = torch.empty((int(L.fsw_unit_table_rows(32)), ldp), dtype=torch.float32, device=dev)
+    out = torch.empty((n, 1 + Sl), dtype=torch.float32, device=dev)
+    _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), Sl, D_FEAT, Xp.data_ptr(), ldp, None, 0, None, stream), "project")
+    _lib.check(L.fsw_unit_coeff_table(fr.data_ptr(), Sl, 32, table.data_ptr(), ldp, stream), "table")
+    a = emb.make_args(graph, st, Xp, ldp, fr, Sl, table, out.data_ptr(), out.stride(0), None, 1.0, 1)
+    a.num_zero_rows = 0
+    kms = timed_ms(lambda: _lib.check(L.fsw_embed_f32(ctypes.byref(a), stream), "embed"), reps, dev)
+    edges = int(graph.rowptr[-1])
+    alg_bytes = 4.0 * edges * Sl + 4.0 * edges + 8.0 * n + 4.0 * st[_lib.STAT_NUM_REG] * (Sl + 1)
+    return {"bound": "hbm", "kernel": "k_embed_reg_unit (rank 0, %d of %d slices)" % (Sl, emb.nSlices),
+            "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "ms_per_launch": kms}
+
+
 def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     """C oracle (port of the reference algorithm) on the host cores: slices [0, nslices) of the same workload."""
     from oracle import c_oracle as C
@@ -240,6 +269,10 @@ def main():
         result["stage_ms"] = ms
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
+    if world > 1:
+        roof = sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)   # every rank runs it
+        if rank == 0:
+            result["roofline"] = roof
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
