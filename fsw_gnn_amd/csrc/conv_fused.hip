@@ -31,6 +31,7 @@ namespace fsw {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFusedRows = 32;
+constexpr int kPipelineMaxDeg = 22;   // two rows of keys + coefficients must fit the 128-VGPR budget
 
 struct FusedArgs {
   const int32_t* rowptr;
@@ -66,7 +67,14 @@ __device__ __forceinline__ float mass_encode_f(float m, int fn) {
   return m;
 }
 
-// phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS
+// phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS.
+// The kernel is bound by memory-level parallelism (bytes in flight per CU), so rows are software-pipelined: the
+// gathers of row r+1 are issued before row r is sorted, and the col indices of row r+2 (wave-uniform scalar loads)
+// are fetched one step earlier still.  The steady-state loop is branch-free so that the compiler's waitcnt for
+// row r leaves the D gathers of row r+1 in flight.
+template <int D>
+struct ColIdx { int c[D > 0 ? D : 1]; };
+
 template <int D>
 __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int nrows, float* __restrict__ H, int chunk) {
   const int lane = lane_id();
@@ -82,20 +90,56 @@ __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int 
     const float* tab = a.table + (int64_t)(D * (D - 1) / 2) * a.ldt + kc;
 #pragma unroll
     for (int t = 0; t < D; ++t) coef[t] = a.out_scale * tab[(int64_t)t * a.ldt];
-    for (int r = 0; r < nrows; ++r) {
-      const int node = a.perm[p + r];
-      const int start = a.rowptr[node];
-      KeyNet<D> net;
+    // lane r holds the CSR offset of the block's row r
+    const int startv = a.rowptr[a.perm[p + min(lane, nrows - 1)]];
+    const float* xk = a.Xp + kc;
+    float* hk = H + a.has_mass + k;
+    auto load_cols = [&](int r, ColIdx<D>& cs) {
+      const int start = __builtin_amdgcn_readlane(startv, r);
 #pragma unroll
-      for (int t = 0; t < D; ++t) {
-        const int c = a.col[start + t];
-        net.k[t] = a.Xp[(int64_t)c * a.ldp + kc];
-      }
+      for (int t = 0; t < D; ++t) cs.c[t] = a.col[start + t];
+    };
+    auto gather = [&](const ColIdx<D>& cs, KeyNet<D>& net) {
+#pragma unroll
+      for (int t = 0; t < D; ++t) net.k[t] = xk[(int64_t)cs.c[t] * a.ldp];
+    };
+    auto finish = [&](KeyNet<D>& net, int r) {
       sort_network<D>(net);
       float acc = b;
 #pragma unroll
       for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
-      if (kvalid) H[r * a.ldh + a.has_mass + k] = acc;
+      if (kvalid) hk[r * a.ldh] = acc;
+    };
+    if constexpr (D <= kPipelineMaxDeg) {
+      ColIdx<D> cA, cB;
+      KeyNet<D> nA, nB;
+      load_cols(0, cA);
+      gather(cA, nA);
+      load_cols(min(1, nrows - 1), cB);
+      int r = 0;
+      for (; r + 2 < nrows; r += 2) {   // at the top: nA in flight for row r, cB = col indices of row r+1
+        gather(cB, nB);
+        load_cols(r + 2, cA);
+        finish(nA, r);
+        gather(cA, nA);
+        load_cols(min(r + 3, nrows - 1), cB);
+        finish(nB, r + 1);
+      }
+      if (r + 1 < nrows) {
+        gather(cB, nB);
+        finish(nA, r);
+        finish(nB, r + 1);
+      } else {
+        finish(nA, r);
+      }
+    } else {
+      for (int r = 0; r < nrows; ++r) {
+        ColIdx<D> cs;
+        KeyNet<D> net;
+        load_cols(r, cs);
+        gather(cs, net);
+        finish(net, r);
+      }
     }
   }
 }
