@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsw_hip.so")
+# FSW_HIP_LIBRARY: another build of the same library (kernel tuning experiments, tools/exp_variants.sh)
+LIB_PATH = os.environ.get("FSW_HIP_LIBRARY") or os.path.join(_HERE, "libfsw_hip.so")
 
 FSW_ABI_VERSION = 1
 REG_MAX_DEG = 32

@@ -25,13 +25,20 @@
 #include <stdlib.h>
 #include "fsw_common.h"
 #include "sortnet.h"
+#include "row_pipeline.h"
+#ifndef FSW_FUSED_PIPE_BARRIER
+#define FSW_FUSED_PIPE_BARRIER 0   // measured: tools/exp_variants.sh
+#endif
 
 namespace fsw {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kFusedRows = 32;
-constexpr int kPipelineMaxDeg = 22;   // two rows of keys + coefficients must fit the 128-VGPR budget
+constexpr int kLdT = 132;   // LDS row stride of the staged output tile (Hout <= 128)
+#ifndef FSW_FUSED_PREFETCH
+#define FSW_FUSED_PREFETCH 8
+#endif
 
 struct FusedArgs {
   const int32_t* rowptr;
@@ -58,6 +65,7 @@ struct FusedArgs {
   float* Y;
   int64_t ldy;
   int ldh;  // LDS row stride of H (odd)
+  int tile_floats;  // LDS floats reserved for H / the staged output tile
   int Kp;
 };
 
@@ -67,14 +75,7 @@ __device__ __forceinline__ float mass_encode_f(float m, int fn) {
   return m;
 }
 
-// phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS.
-// The kernel is bound by memory-level parallelism (bytes in flight per CU), so rows are software-pipelined: the
-// gathers of row r+1 are issued before row r is sorted, and the col indices of row r+2 (wave-uniform scalar loads)
-// are fetched one step earlier still.  The steady-state loop is branch-free so that the compiler's waitcnt for
-// row r leaves the D gathers of row r+1 in flight.
-template <int D>
-struct ColIdx { int c[D > 0 ? D : 1]; };
-
+// phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS (row_pipeline.h)
 template <int D>
 __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int nrows, float* __restrict__ H, int chunk) {
   const int lane = lane_id();
@@ -90,57 +91,18 @@ __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int 
     const float* tab = a.table + (int64_t)(D * (D - 1) / 2) * a.ldt + kc;
 #pragma unroll
     for (int t = 0; t < D; ++t) coef[t] = a.out_scale * tab[(int64_t)t * a.ldt];
-    // lane r holds the CSR offset of the block's row r
-    const int startv = a.rowptr[a.perm[p + min(lane, nrows - 1)]];
-    const float* xk = a.Xp + kc;
-    float* hk = H + a.has_mass + k;
-    auto load_cols = [&](int r, ColIdx<D>& cs) {
-      const int start = __builtin_amdgcn_readlane(startv, r);
+    const int startv = a.rowptr[a.perm[p + min(lane, nrows - 1)]];   // lane r: CSR offset of the block's row r
+    float* hk = H + a.has_mass + kc;   // lanes past the last slice recompute slice S-1 (row_pipeline.h)
+    const int ldh = a.ldh;
+    pipelined_rows<D, pipeline_depth<D>(), FSW_FUSED_PIPE_BARRIER>(
+        nrows, a.col, a.Xp + kc, a.ldp, [&](int r) { return __builtin_amdgcn_readlane(startv, r); },
+        [&](KeyNet<D>& net, int r) {
+          sort_network<D>(net);
+          float acc = b;
 #pragma unroll
-      for (int t = 0; t < D; ++t) cs.c[t] = a.col[start + t];
-    };
-    auto gather = [&](const ColIdx<D>& cs, KeyNet<D>& net) {
-#pragma unroll
-      for (int t = 0; t < D; ++t) net.k[t] = xk[(int64_t)cs.c[t] * a.ldp];
-    };
-    auto finish = [&](KeyNet<D>& net, int r) {
-      sort_network<D>(net);
-      float acc = b;
-#pragma unroll
-      for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
-      if (kvalid) hk[r * a.ldh] = acc;
-    };
-    if constexpr (D <= kPipelineMaxDeg) {
-      ColIdx<D> cA, cB;
-      KeyNet<D> nA, nB;
-      load_cols(0, cA);
-      gather(cA, nA);
-      load_cols(min(1, nrows - 1), cB);
-      int r = 0;
-      for (; r + 2 < nrows; r += 2) {   // at the top: nA in flight for row r, cB = col indices of row r+1
-        gather(cB, nB);
-        load_cols(r + 2, cA);
-        finish(nA, r);
-        gather(cA, nA);
-        load_cols(min(r + 3, nrows - 1), cB);
-        finish(nB, r + 1);
-      }
-      if (r + 1 < nrows) {
-        gather(cB, nB);
-        finish(nA, r);
-        finish(nB, r + 1);
-      } else {
-        finish(nA, r);
-      }
-    } else {
-      for (int r = 0; r < nrows; ++r) {
-        ColIdx<D> cs;
-        KeyNet<D> net;
-        load_cols(r, cs);
-        gather(cs, net);
-        finish(net, r);
-      }
-    }
+          for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
+          hk[r * ldh] = acc;
+        });
   }
 }
 
@@ -148,11 +110,48 @@ __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int 
   X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
   X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
+// phase 2 for one 32-column slab: acc = H[32 x Kp] . W1^T[Kp x 32] on the fp32 matrix cores
+template <int ABL>
+__device__ __forceinline__ void slab_mma(const FusedArgs& a, const float* __restrict__ H, int slab, int fr, int fh, f32x16& acc) {
+  constexpr int kPrefetch = FSW_FUSED_PREFETCH;   // 16-byte W loads in flight per wave (they queue behind the CU's HBM gathers)
+  const int ngroups = a.Kp >> 3;
+  const int j = min(slab * 32 + fr, (int)a.ldw - 1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* hp = H + fr * a.ldh + fh;
+  // packed W1^T: group g of this lane at wq[g * gstride]; the host pads 16 zero groups past the end
+  const float4* wq = reinterpret_cast<const float4*>(a.Wq) + ((int64_t)j * 2 + fh);
+  const int64_t gstride = a.ldw * 2;
+  auto mma4 = [&](const float* h, const float4& bq) {
+    if constexpr (ABL & 1) { asm volatile("" ::"v"(bq.x), "v"(bq.y), "v"(bq.z), "v"(bq.w)); return; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], bq.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], bq.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[4], bq.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[6], bq.w, acc, 0, 0, 0);
+  };
+  float4 bq[kPrefetch];
+#pragma unroll
+  for (int u = 0; u < kPrefetch; ++u) bq[u] = wq[u * gstride];
+  wq += kPrefetch * gstride;
+  int g0 = 0;
+  for (; g0 + kPrefetch <= ngroups; g0 += kPrefetch) {
+#pragma unroll
+    for (int u = 0; u < kPrefetch; ++u) {
+      mma4(hp + 8 * (g0 + u), bq[u]);
+      bq[u] = wq[u * gstride];
+    }
+    wq += kPrefetch * gstride;
+  }
+#pragma unroll
+  for (int u = 0; u < kPrefetch; ++u)
+    if (g0 + u < ngroups) mma4(hp + 8 * (g0 + u), bq[u]);
+}
+
 template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0>  // ABL: timing experiments only (tools/exp_fused.py)
 __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;                                                        // [kFusedRows][ldh]
-  int* nodeS = reinterpret_cast<int*>(smem + kFusedRows * a.ldh);         // [kFusedRows]
+  int* nodeS = reinterpret_cast<int*>(smem + a.tile_floats);              // [kFusedRows]
 
   // workgroup -> (degree bin, perm range): one degree per workgroup, highest degrees first, bin 0 last
   int D, p = 0, pe = 0;
@@ -198,68 +197,63 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
         break;
     }
   }
-  // Rows of Yin (= x . W2^T + b, stored by the projection kernel in perm order, so this workgroup's 32 rows are one
-  // contiguous run) that this wave's first output slab needs.  Issued after phase 1 (registers are free again) and before
-  // the barrier, so the reads are in flight while the workgroup's other waves finish their rows.
-  float yin[16];
-  {
-    const int j = wv * 32 + fr;
+  const int nslabs = (a.Hout + 31) / 32;
+  if (nslabs <= 4) {
+    // ---- Hout <= 128: one slab per wave, output tile staged through LDS so that Y is written as whole rows ----
+    // Rows of Yin (= x . W2^T + b, stored by the projection kernel in perm order: this workgroup's 32 rows are one
+    // contiguous run).  Wave w finishes rows 8w..8w+7; lane owns columns lane and lane+64.  Issued after phase 1
+    // (registers are free again) and before the barrier: in flight while the other waves finish their rows.
+    float yin[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = wv * 8 + (q >> 1), c = lane + 64 * (q & 1);
+      yin[q] = 0.f;
+      if ((ABL & 2) == 0 && a.Yin && row < nrows && c < a.Hout) yin[q] = a.Yin[(int64_t)(p + row) * a.ldyin + c];
+    }
+    __syncthreads();
+    f32x16 acc;
+    if (wv < nslabs) slab_mma<ABL>(a, H, wv, fr, fh, acc);
+    __syncthreads();                         // every wave has finished reading H: reuse it for the output tile
+    float* T = smem;                         // [kFusedRows][kLdT]
+    if (wv < nslabs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * fh) * kLdT + wv * 32 + fr] = acc[r];
+    }
+    __syncthreads();
+    float lb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) lb[h] = (!a.Yin && a.lin_bias && lane + 64 * h < a.Hout) ? a.lin_bias[lane + 64 * h] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wv * 8 + rr;
+      const int node = nodeS[row];
+      if (node < 0) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        if (c < a.Hout) {
+          float y = T[row * kLdT + c] + lb[h] + yin[rr * 2 + h];
+          if (a.act == 1) y = fmaxf(y, 0.f);
+          else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
+          if ((ABL & 4) == 0 || y == 12345.f) a.Y[(int64_t)node * a.ldy + c] = y;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- wide layers (Hout > 128): slabs round-robin over the waves, every wave stores its own 32 x 32 tiles ----
+  __syncthreads();
+  for (int slab = wv; slab < nslabs; slab += 4) {
+    const int j = slab * 32 + fr;
+    float yin[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;     // C/D map of the 32x32 MFMA
-      yin[r] = 0.f;
-      if ((ABL & 2) == 0 && a.Yin && row < nrows && j < a.Hout) yin[r] = a.Yin[(int64_t)(p + row) * a.ldyin + j];
-    }
-  }
-
-  __syncthreads();
-
-  // phase 2 + 3: Y tile = H . W1^T, one 32-column slab per wave and iteration
-  const int nslabs = (a.Hout + 31) / 32;
-  const int ngroups = a.Kp >> 3;
-  constexpr int kPrefetch = 8;   // 16-byte W loads in flight per wave (they queue behind the CU's HBM gathers)
-  for (int slab = wv; slab < nslabs; slab += 4) {
-    const int j0 = slab * 32;
-    const int j = j0 + fr;
-    if (slab != wv) {            // later slabs of wide layers: Y rows loaded here
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int node = nodeS[(r & 3) + 8 * (r >> 2) + 4 * fh];
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-        yin[r] = (a.Yin && node >= 0 && j < a.Hout) ? a.Yin[(int64_t)(p + row) * a.ldyin + j] : 0.f;
-      }
+      yin[r] = (a.Yin && row < nrows && j < a.Hout) ? a.Yin[(int64_t)(p + row) * a.ldyin + j] : 0.f;
     }
     f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* hp = H + fr * a.ldh + fh;
-    // packed W1^T: group g of this lane at wq[g * gstride]; the host pads kPrefetch zero groups past the end
-    const float4* wq = reinterpret_cast<const float4*>(a.Wq) + ((int64_t)j * 2 + fh);
-    const int64_t gstride = a.ldw * 2;
-    auto mma4 = [&](const float* h, const float4& bq) {
-      if constexpr (ABL & 1) { asm volatile("" ::"v"(bq.x), "v"(bq.y), "v"(bq.z), "v"(bq.w)); return; }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[0], bq.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[2], bq.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[4], bq.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[6], bq.w, acc, 0, 0, 0);
-    };
-    float4 bq[kPrefetch];
-#pragma unroll
-    for (int u = 0; u < kPrefetch; ++u) bq[u] = wq[u * gstride];
-    wq += kPrefetch * gstride;
-    int g0 = 0;
-    for (; g0 + kPrefetch <= ngroups; g0 += kPrefetch) {
-#pragma unroll
-      for (int u = 0; u < kPrefetch; ++u) {
-        mma4(hp + 8 * (g0 + u), bq[u]);
-        bq[u] = wq[u * gstride];
-      }
-      wq += kPrefetch * gstride;
-    }
-#pragma unroll
-    for (int u = 0; u < kPrefetch; ++u)
-      if (g0 + u < ngroups) mma4(hp + 8 * (g0 + u), bq[u]);
-
+    slab_mma<ABL>(a, H, slab, fr, fh, acc);
     if (j < a.Hout) {
       const float lb = (!a.Yin && a.lin_bias) ? a.lin_bias[j] : 0.f;
 #pragma unroll
@@ -269,7 +263,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
           float y = acc[r] + lb + yin[r];
           if (a.act == 1) y = fmaxf(y, 0.f);
           else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
-          if ((ABL & 4) == 0 || y == 12345.f) a.Y[(int64_t)node * a.ldy + j] = y;
+          a.Y[(int64_t)node * a.ldy + j] = y;
         }
       }
     }
@@ -283,7 +277,7 @@ using namespace fsw;
 extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
   const int Kp = (has_mass + S + 7) & ~7;
   const int ldh = Kp | 1;
-  return (size_t)kFusedRows * ldh * sizeof(float) + kFusedRows * sizeof(int);
+  return (size_t)kFusedRows * (ldh > kLdT ? ldh : kLdT) * sizeof(float) + kFusedRows * sizeof(int);
 }
 
 extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
@@ -311,6 +305,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   a.Y = Y; a.ldy = ldy;
   a.Kp = (e.has_mass + e.S + 7) & ~7;
   a.ldh = a.Kp | 1;
+  a.tile_floats = kFusedRows * (a.ldh > kLdT ? a.ldh : kLdT);
   // two launches: long rows first (more registers per wave), then degrees 0..16 at higher occupancy
   const int64_t nblocks = ceil_div(e.num_rows, kFusedRows) + FSW_REG_MAX_DEG + 1;
 #ifdef FSW_ABLATION

@@ -20,6 +20,10 @@
 //                            the reference's 2 w sinc(xi w) cos(pi xi (2c - w)) by sum-to-product.
 #include "fsw_common.h"
 #include "sortnet.h"
+#include "row_pipeline.h"
+#ifndef FSW_REG_PIPE_BARRIER
+#define FSW_REG_PIPE_BARRIER 1   // measured: tools/exp_variants.sh
+#endif
 
 namespace fsw {
 
@@ -88,30 +92,29 @@ __device__ __forceinline__ void unit_run(int p, int pe, const int32_t* __restric
                                          const int32_t* __restrict__ perm, const float* __restrict__ Xp, int64_t ldp,
                                          const float* __restrict__ table, int64_t ldt, float* __restrict__ out, int64_t ldo,
                                          const float* __restrict__ bias, float out_scale, int has_mass, int mass_fn,
-                                         float mass_scale, int k, int kc, bool kvalid, bool mass_lane) {
+                                         float mass_scale, int kc, bool mass_lane_wave) {
   float coef[D];
   const float* tab = table + (int64_t)(D * (D - 1) / 2) * ldt + kc;
 #pragma unroll
   for (int t = 0; t < D; ++t) coef[t] = out_scale * tab[(int64_t)t * ldt];
   const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
-  const float massv = out_scale * (mass_encode((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
-  for (; p < pe; ++p) {
-    const int node = perm[p];
-    const int start = rowptr[node];
-    KeyNet<D> net;
+  const int nrows = pe - p;
+  const int lane = lane_id();
+  const int nodev = perm[p + min(lane, nrows - 1)];   // lane r: node id and CSR offset of the block's row r
+  const int startv = rowptr[nodev];
+  if (mass_lane_wave && lane < nrows)
+    out[(int64_t)nodev * ldo] = out_scale * (mass_encode((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+  // lanes past the last slice recompute slice S-1 and store the same value to the same address (row_pipeline.h)
+  float* ok = out + has_mass + kc;
+  pipelined_rows<D, pipeline_depth<D>(), FSW_REG_PIPE_BARRIER>(
+      nrows, col, Xp + kc, ldp, [&](int r) { return __builtin_amdgcn_readlane(startv, r); },
+      [&](KeyNet<D>& net, int r) {
+        sort_network<D>(net);
+        float acc = b;
 #pragma unroll
-    for (int t = 0; t < D; ++t) {
-      const int c = col[start + t];
-      net.k[t] = Xp[(int64_t)c * ldp + kc];
-    }
-    sort_network<D>(net);
-    float acc = b;
-#pragma unroll
-    for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
-    float* orow = out + (int64_t)node * ldo;
-    if (kvalid) orow[has_mass + k] = acc;
-    if (mass_lane) orow[0] = massv;
-  }
+        for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
+        ok[(int64_t)__builtin_amdgcn_readlane(nodev, r) * ldo] = acc;
+      });
 }
 
 #define FSW_CASES_1_32(X)                                                                                              \
@@ -129,14 +132,13 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit(const int32_t* __restric
   const int k = chunk * kWave + lane_id();
   const bool kvalid = k < S;
   const int kc = kvalid ? k : S - 1;
-  const bool mass_lane = has_mass && k == 0;
   int D, p, pe;
   if (!block_range(bin_start, D, p, pe)) return;
   switch (D) {
 #define X(d)                                                                                                          \
   case d:                                                                                                             \
     unit_run<d>(p, pe, rowptr, col, perm, Xp, ldp, table, ldt, out, ldo, bias, out_scale, has_mass, mass_fn,          \
-                mass_scale, k, kc, kvalid, mass_lane);                                                                \
+                mass_scale, kc, has_mass && chunk == 0);                                                              \
     break;
     FSW_CASES_1_32(X)
 #undef X
