@@ -366,6 +366,12 @@ __global__ void k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __
   }
 }
 
+// A workgroup places kBinRowsPerBlock consecutive rows: per-bin counts accumulate in LDS over the rounds (a lane's rank
+// is the running count before its round + its rank among its wave peers), then ONE global atomic per bin claims the
+// workgroup's range -- the 35 cursors are shared by every workgroup, so same-address atomics are the cost to keep low.
+constexpr int kBinItems = 8;
+constexpr int kBinRowsPerBlock = 256 * kBinItems;
+
 __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ rowptr, int64_t n,
                                                   int32_t* __restrict__ bin_cursor, int32_t* __restrict__ perm,
                                                   int32_t* __restrict__ invperm) {
@@ -373,20 +379,30 @@ __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ ro
   __shared__ int lbase[FSW_NUM_BINS];
   if (threadIdx.x < FSW_NUM_BINS) lcount[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = r < n;
-  const int bin = valid ? degree_bin(rowptr[r + 1] - rowptr[r]) : 0;
-  const unsigned long long peers = match_bin(bin, valid);
-  const int leader = __ffsll((long long)peers) - 1;
-  int prev = 0;
-  if (valid && lane_id() == leader) prev = atomicAdd(&lcount[bin], __popcll(peers));   // one LDS atomic per bin and wave
-  const int rank = __shfl(prev, leader) + __popcll(peers & ((1ull << lane_id()) - 1ull));
+  const int64_t r0 = (int64_t)blockIdx.x * kBinRowsPerBlock + threadIdx.x;
+  int bin[kBinItems], rank[kBinItems];
+#pragma unroll
+  for (int i = 0; i < kBinItems; ++i) {
+    const int64_t r = r0 + (int64_t)i * 256;
+    const bool valid = r < n;
+    bin[i] = valid ? degree_bin(rowptr[r + 1] - rowptr[r]) : 0;
+    const unsigned long long peers = match_bin(bin[i], valid);
+    const int leader = __ffsll((long long)peers) - 1;
+    int prev = 0;
+    if (valid && lane_id() == leader) prev = atomicAdd(&lcount[bin[i]], __popcll(peers));   // one LDS atomic per bin and wave
+    rank[i] = __shfl(prev, leader) + __popcll(peers & ((1ull << lane_id()) - 1ull));
+  }
   __syncthreads();
   if (threadIdx.x < FSW_NUM_BINS && lcount[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], lcount[threadIdx.x]);
   __syncthreads();
-  if (valid) {
-    perm[lbase[bin] + rank] = (int32_t)r;
-    if (invperm) invperm[r] = lbase[bin] + rank;
+#pragma unroll
+  for (int i = 0; i < kBinItems; ++i) {
+    const int64_t r = r0 + (int64_t)i * 256;
+    if (r < n) {
+      const int pos = lbase[bin[i]] + rank[i];
+      perm[pos] = (int32_t)r;
+      if (invperm) invperm[r] = pos;
+    }
   }
 }
 
@@ -542,12 +558,12 @@ __global__ void __launch_bounds__(256) k_rowptr_from_keys(const uint32_t* __rest
 
 static int finish_bins(int32_t* rowptr, int64_t num_rows, int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats,
                        GraphWs& g, hipStream_t stream) {
-  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 256 * 16);
+  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 512);   // few workgroups: each ends in 35 same-address atomics
   k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, g.bin_count, stats);
   FSW_LAUNCH_CHECK();
   k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
   FSW_LAUNCH_CHECK();
-  k_bin_rows<<<(int)ceil_div(num_rows, 256), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
+  k_bin_rows<<<(int)ceil_div(num_rows, kBinRowsPerBlock), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
   FSW_LAUNCH_CHECK();
   return 0;
 }
