@@ -11,10 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FSW_HIP_LIBRARY: another build of the same library (kernel tuning experiments, tools/exp_variants.sh)
 LIB_PATH = os.environ.get("FSW_HIP_LIBRARY") or os.path.join(_HERE, "libfsw_hip.so")
 
-FSW_ABI_VERSION = 1
+FSW_ABI_VERSION = 2
 REG_MAX_DEG = 32
 LDS_MAX_DEG = 2048
-NUM_BINS = REG_MAX_DEG + 3
+MID_SIZES = (40, 48, 64, 80, 96, 128, 160, 192, 256)   # FSW_MID_SIZES: padded register-path networks above REG_MAX_DEG
+NUM_LDS_BINS = 3                                          # FSW_NUM_LDS_BINS: degrees <= 512, 1024, 2048
+NUM_BINS = REG_MAX_DEG + 1 + len(MID_SIZES) + NUM_LDS_BINS + 1
 NUM_STATS = 8
 STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL, STAT_NNZ = 0, 1, 2, 3, 4, 5, 6
 FLAG_INDEX_RANGE, FLAG_W_NONFINITE, FLAG_W_NEGATIVE, FLAG_X_NONFINITE = 1, 2, 4, 8

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) k_embed_long(const int32_t* __restrict__ 
                                                     float out_scale, int has_mass, int mass_fn, float mass_scale,
                                                     char* __restrict__ scratch, int64_t scratch_per_wg,
                                                     const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve,
-                                                    int d_edge) {
+                                                    int d_edge, int bin_lo, int bin_hi) {
   using E = Elem<WEIGHTED>;
   using T = typename E::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,8 +141,7 @@ __global__ void __launch_bounds__(256) k_embed_long(const int32_t* __restrict__ 
     tile = reinterpret_cast<T*>(smem + head);
     tile_bytes = kLdsBytes - head;
   }
-  const int bin = GLOBAL ? FSW_BIN_GLOBAL : FSW_BIN_LDS;
-  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];   // rows of the degree bins bin_lo .. bin_hi
   const int lane = lane_id(), wv = threadIdx.x >> 6;
 
   for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
@@ -290,7 +289,7 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
                                                         float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
                                                         char* __restrict__ scratch, int64_t scratch_per_wg,
                                                         const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve,
-                                                        int d_edge, float* __restrict__ gkey, int64_t ldk) {
+                                                        int d_edge, float* __restrict__ gkey, int64_t ldk, int bin_lo, int bin_hi) {
   using E = Elem<true>;
   using T = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,8 +297,7 @@ __global__ void __launch_bounds__(256) k_embed_long_bwd(const int32_t* __restric
   constexpr int head = WEIGHTED ? kLdsWeightFloats * 4 : 0;
   char* tile_base = GLOBAL ? scratch + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * scratch_per_wg : smem + head;
   const int tile_bytes = GLOBAL ? 0 : kLdsBytes - head;
-  const int bin = GLOBAL ? FSW_BIN_GLOBAL : FSW_BIN_LDS;
-  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];   // rows of the degree bins bin_lo .. bin_hi
   const int lane = lane_id(), wv = threadIdx.x >> 6;
   __shared__ double msum[4];
 
@@ -429,7 +427,8 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
   k_embed_long_bwd<WGT, GLB><<<grid, 256, (GLB) ? 1024 : kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, \
                                                                              a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass,   \
                                                                              a.out_scale, gXp, ldgp, gfreq, scratch, per_wg,   \
-                                                                             a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk)
+                                                                             a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk,        \
+                                                                             (GLB) ? FSW_BIN_GLOBAL : FSW_BIN_MID0, (GLB) ? FSW_BIN_GLOBAL : FSW_BIN_GLOBAL - 1)
   if (global) {
     if (unit) FSW_LAUNCH_LONG_BWD(false, true);
     else FSW_LAUNCH_LONG_BWD(true, true);
@@ -452,21 +451,6 @@ size_t embed_global_scratch_bytes(int64_t max_degree) {
   return embed_global_scratch_per_wg(max_degree) * kGlobalWgs * kSplitY;
 }
 
-int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
-  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
-  dim3 grid((unsigned)std::min<int64_t>(rows_upper, 1 << 16), kSplitY);
-  if (unit_fast)
-    k_embed_long<false, false><<<grid, 256, kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-                                                                 a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,
-                                                                 a.mass_fn, a.mass_scale, nullptr, 0, a.efeat, a.Ve, a.ldve, a.d_edge);
-  else
-    k_embed_long<true, false><<<grid, 256, kLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-                                                                a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,
-                                                                a.mass_fn, a.mass_scale, nullptr, 0, a.efeat, a.Ve, a.ldve, a.d_edge);
-  FSW_LAUNCH_CHECK();
-  return 0;
-}
-
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
   // the caller sized the scratch with fsw_embed_scratch_bytes(max_degree): kGlobalWgs * kSplitY equal parts
@@ -479,11 +463,11 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
   if (unit_fast)
     k_embed_long<false, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
                                                            a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                           a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge);
+                                                           a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL);
   else
     k_embed_long<true, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
                                                           a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                          a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge);
+                                                          a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL);
   FSW_LAUNCH_CHECK();
   return 0;
 }

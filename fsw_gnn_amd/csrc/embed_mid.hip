@@ -1,0 +1,194 @@
+// Fused neighbourhood kernels, register path for mid-degree rows (FSW_REG_MAX_DEG < in-degree <= FSW_MID_MAX_DEG).  gfx950.
+//
+// Same mapping as embed_reg.hip -- one wavefront per recipient row and 64-slice chunk, lane = slice, one coalesced
+// 256-byte gather of Xp[col, k0..k0+63] per neighbour, the whole neighbourhood in registers -- extended to rows of up
+// to 256 neighbours: at one wave per SIMD a lane owns 512 registers, and a register-resident Batcher network costs
+// ~11 min/max pairs per key at 128 keys, which the matrix-free VALU retires in about the time HBM needs to deliver
+// the 256 bytes of that key's gather.  (The LDS bitonic path, which these rows took before, spends a barrier and an
+// LDS round trip per network stage: 72 GB/s of gather against ~4.7 TB/s here on an RMAT graph, tools/exp_skew.py.)
+//   * rows are binned by padded network size (FSW_MID_SIZES); a kernel instance sorts DP wires, wires >= D hold +inf
+//     and never receive a coefficient;
+//   * unit weights, tau <= 1: the coefficients (1+xi)[sin(2 pi xi (r+1)/D) - sin(2 pi xi r/D)]/(pi xi) (reference
+//     fsw_embedding.py:1047-1075, 1109) come from a float64 rotation recurrence per (row, slice) -- a (D, r, slice)
+//     table as on the <= 32 path would not fit -- so there is still no transcendental per element;
+//   * general weights: (key, weight) network, the reference's pad element (fsw_embedding.py:787-821) at wire D,
+//     cumulative weight and phase in float64 as in embed_reg.hip.
+#include "fsw_common.h"
+#include <algorithm>
+#include "sortnet.h"
+
+namespace fsw {
+
+constexpr double kPiM = 3.14159265358979323846;
+
+__device__ __forceinline__ float mass_encode_m(float m, int fn) {
+  // reference fsw_embedding.py:857-865
+  if (fn == 1) return 2.f * (m / (sqrtf(m + 1.f) + 1.f));
+  if (fn == 2) return log1pf(m);
+  return m;
+}
+
+__device__ __forceinline__ float sin2pi_rev_m(double x) {
+  const double r = x - rint(x);
+  return sinpif(2.f * (float)r);
+}
+
+template <int DP>
+__global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
+                                                        int bin, const float* __restrict__ Xp, int64_t ldp, int S,
+                                                        const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo,
+                                                        const float* __restrict__ bias, float out_scale, int has_mass,
+                                                        int mass_fn, float mass_scale) {
+  const int chunk = blockIdx.y * 4 + wave_id();
+  if (chunk * kWave >= S) return;
+  const int kc = min(chunk * kWave + lane_id(), S - 1);   // lanes past the last slice recompute slice S-1 (same value, same address)
+  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  const float xif = freqs[kc];
+  const double xi = (double)xif;
+  const bool lin = xif < 1e-30f;   // xi == 0: Delta_t = 2 w_t
+  const double scale = lin ? 0.0 : (double)out_scale * (1.0 + xi) / (kPiM * xi);
+  const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
+  const float* xk = Xp + kc;
+  for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;   // FSW_REG_MAX_DEG < D <= DP
+    KeyNet<DP> net;
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      net.k[t] = __builtin_inff();
+      if (t < D) net.k[t] = xk[(int64_t)col[start + t] * ldp];
+    }
+    sort_network<DP>(net);
+    float acc = b;
+    if (lin) {
+      const float coef = out_scale * 2.f / (float)D;
+#pragma unroll
+      for (int r = 0; r < DP; ++r)
+        if (r < D) acc = fmaf(coef, net.k[r], acc);
+    } else {
+      // s_r = sin(2 pi xi r / D) by rotation in float64: error ~ r * 2^-53
+      const double step = xi / (double)D;
+      double sd, cd;
+      sincospi(2.0 * (step - rint(step)), &sd, &cd);
+      double c = 1.0, s = 0.0;
+#pragma unroll
+      for (int r = 0; r < DP; ++r) {
+        if (r < D) {
+          const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
+          acc = fmaf((float)(scale * (sn - s)), net.k[r], acc);
+          s = sn;
+          c = cn;
+        }
+      }
+    }
+    float* orow = out + (int64_t)node * ldo;
+    orow[has_mass + kc] = acc;
+    if (has_mass && chunk == 0 && lane_id() == 0)
+      orow[0] = out_scale * (mass_encode_m((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+  }
+}
+
+// DP = padded degree + 1: wire D carries the reference's pad element
+template <int DP>
+__global__ void __launch_bounds__(256) k_embed_mid_weighted(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ bin_start, int bin,
+                                                            const float* __restrict__ Xp, int64_t ldp, int S,
+                                                            const float* __restrict__ freqs, float tau, float* __restrict__ out,
+                                                            int64_t ldo, const float* __restrict__ bias, float out_scale,
+                                                            int has_mass, int mass_fn, float mass_scale,
+                                                            const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                            int64_t ldve, int d_edge) {
+  const int chunk = blockIdx.y * 4 + wave_id();
+  if (chunk * kWave >= S) return;
+  const int kc = min(chunk * kWave + lane_id(), S - 1);
+  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  const float xif = freqs[kc];
+  const double xi = (double)xif;
+  const bool lin = xif < 1e-30f;
+  const float scale = lin ? 2.f : (float)((1.0 + xi) / (kPiM * xi));
+  const float b = bias ? bias[has_mass + kc] : 0.f;
+  const double taud = (double)tau;
+  for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;   // D + 1 <= DP
+    PairNet<DP> net;
+    double m = 0.0;
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      net.k[t] = __builtin_inff();
+      net.w[t] = 0.f;
+      if (t < D) {
+        const float wt = w ? w[start + t] : 1.f;
+        float key = Xp[(int64_t)col[start + t] * ldp + kc];
+        if (efeat) {   // edge features: + <e_ij, v_k[d_in:]> (reference fsw_embedding.py:934-968)
+          const float* er = efeat + (int64_t)(start + t) * d_edge;
+          const float* vr = Ve + (int64_t)kc * ldve;
+          for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+        }
+        net.k[t] = key;
+        net.w[t] = wt;
+        m += (double)wt;
+      }
+    }
+    const float padw = (float)fmax(taud - m, 0.0);   // zero weight when the row is not deficient
+#pragma unroll
+    for (int t = FSW_REG_MAX_DEG + 1; t < DP; ++t)
+      if (t == D) {
+        net.k[t] = 0.f;                              // the reference's pad element at x = 0
+        net.w[t] = padw;
+      }
+    const double inv = 1.0 / fmax(m, taud);
+    sort_network<DP>(net);
+    double c = 0.0;
+    float sprev = 0.f, acc = 0.f, acc0 = 0.f;
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      if (t <= D) {
+        c += (double)net.w[t];
+        const float s = sin2pi_rev_m(xi * (c * inv));
+        acc = fmaf(s - sprev, net.k[t], acc);
+        acc0 = fmaf(net.w[t], net.k[t], acc0);
+        sprev = s;
+      }
+    }
+    const float val = lin ? acc0 * (float)inv : acc;
+    float* orow = out + (int64_t)node * ldo;
+    orow[has_mass + kc] = out_scale * (scale * val + b);
+    if (has_mass && chunk == 0 && lane_id() == 0)
+      orow[0] = out_scale * (mass_encode_m((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+  }
+}
+
+// rows_upper: upper bound of the rows in the mid bins (the per-bin counts stay on the device); surplus workgroups of
+// an instance whose bin is short or empty leave at once.
+int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper, hipStream_t stream) {
+  if (rows_upper <= 0) return 0;
+  dim3 grid((unsigned)std::min<int64_t>(rows_upper, 8192), (unsigned)ceil_div(a.S, 4 * kWave));
+#define FSW_MID_UNIT(i, DP)                                                                                               \
+  k_embed_mid_unit<DP><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S,  \
+                                                 a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,       \
+                                                 a.mass_scale);                                                           \
+  FSW_LAUNCH_CHECK()
+#define FSW_MID_WEIGHTED(i, DP)                                                                                           \
+  k_embed_mid_weighted<DP + 1><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp,  \
+                                                         a.ldp, a.S, a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale,   \
+                                                         a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve,      \
+                                                         a.d_edge);                                                       \
+  FSW_LAUNCH_CHECK()
+  if (unit_fast) {
+    FSW_MID_UNIT(0, 40); FSW_MID_UNIT(1, 48); FSW_MID_UNIT(2, 64); FSW_MID_UNIT(3, 80); FSW_MID_UNIT(4, 96);
+    FSW_MID_UNIT(5, 128); FSW_MID_UNIT(6, 160); FSW_MID_UNIT(7, 192); FSW_MID_UNIT(8, 256);
+  } else {   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the LDS path (embed_lds.hip)
+    FSW_MID_WEIGHTED(0, 40); FSW_MID_WEIGHTED(1, 48); FSW_MID_WEIGHTED(2, 64); FSW_MID_WEIGHTED(3, 80);
+    FSW_MID_WEIGHTED(4, 96); FSW_MID_WEIGHTED(5, 128);
+  }
+#undef FSW_MID_UNIT
+#undef FSW_MID_WEIGHTED
+  return 0;
+}
+
+}  // namespace fsw

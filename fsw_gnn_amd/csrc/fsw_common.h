@@ -37,8 +37,15 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ int degree_bin(int deg) {
-  return deg <= FSW_REG_MAX_DEG ? deg : (deg <= FSW_LDS_MAX_DEG ? FSW_BIN_LDS : FSW_BIN_GLOBAL);
+__host__ __device__ inline int degree_bin(int deg) {
+  if (deg <= FSW_REG_MAX_DEG) return deg;
+  if (deg > FSW_LDS_MAX_DEG) return FSW_BIN_GLOBAL;
+  if (deg > FSW_MID_MAX_DEG) return FSW_BIN_LDS0 + (deg > 512) + (deg > 1024);
+  constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
+  int i = 0;
+#pragma unroll
+  for (int j = 0; j < FSW_NUM_MID_BINS - 1; ++j) i += deg > sizes[j];
+  return FSW_BIN_MID0 + i;
 }
 
 __host__ __device__ inline uint32_t pow2ceil(uint32_t v) {
@@ -46,5 +53,7 @@ __host__ __device__ inline uint32_t pow2ceil(uint32_t v) {
   while (p < v) p <<= 1;
   return p;
 }
+
+static_assert(FSW_NUM_LDS_BINS == 3 && FSW_MID_MAX_DEG == 256 && FSW_LDS_MAX_DEG == 2048, "degree_bin assumes LDS bins 512 / 1024 / 2048");
 
 }  // namespace fsw

@@ -314,8 +314,9 @@ __global__ void __launch_bounds__(256) k_finish_csr(const uint32_t* __restrict__
 __device__ __forceinline__ unsigned long long match_bin(int bin, bool valid) {
   unsigned long long peers = __ballot(valid);
   if (!valid) peers = ~peers;
+  static_assert(FSW_NUM_BINS <= 64, "bin ids must fit 6 bits");
 #pragma unroll
-  for (int b = 0; b < 6; ++b) {   // FSW_NUM_BINS = 35 < 64
+  for (int b = 0; b < 6; ++b) {
     const unsigned long long bb = __ballot((bin >> b) & 1);
     peers &= ((bin >> b) & 1) ? bb : ~bb;
   }
@@ -361,7 +362,9 @@ __global__ void k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __
     bin_start[FSW_NUM_BINS] = acc;
     stats[FSW_STAT_NUM_ZERO_DEG] = bin_count[0];
     stats[FSW_STAT_NUM_REG] = reg;
-    stats[FSW_STAT_NUM_LDS] = bin_count[FSW_BIN_LDS];
+    int mid = 0;
+    for (int b = FSW_BIN_MID0; b < FSW_BIN_GLOBAL; ++b) mid += bin_count[b];
+    stats[FSW_STAT_NUM_LDS] = mid;
     stats[FSW_STAT_NUM_GLOBAL] = bin_count[FSW_BIN_GLOBAL];
   }
 }

@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int B3_LD = 136;  // bf16 per LDS row: 128 + 8 (16-byte pad)
+#ifndef FSW_PROJECT_ABL
+#define FSW_PROJECT_ABL 0   // timing experiments (tools/exp_variants.sh): 1 = no MFMA, 2 = no output stores
+#endif
 
 __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
   a = (__bf16)v;
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (slab_active) {
+    if (slab_active && !(FSW_PROJECT_ABL & 1)) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][0][fr][16 * s + 8 * fh]);
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
       for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
     }
     __syncthreads();
-    write_out(buf, tile);
+    if (!(FSW_PROJECT_ABL & 2)) write_out(buf, tile);
     buf ^= 1;
   }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);

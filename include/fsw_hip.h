@@ -33,25 +33,37 @@ extern "C" {
 
 typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
 
-#define FSW_ABI_VERSION 1
+#define FSW_ABI_VERSION 2
 
 /* Degree classes of the fused neighbourhood kernels.  Rows are binned by in-degree:
  *   bin b, 0 <= b <= FSW_REG_MAX_DEG : rows of degree exactly b (register path, one wave per row and
  *                                      64-slice chunk, exact-size sorting network)
- *   bin FSW_BIN_LDS                  : FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (LDS bitonic path)
- *   bin FSW_BIN_GLOBAL               : degree > FSW_LDS_MAX_DEG (global-scratch bitonic path)        */
+ *   bin FSW_BIN_MID0 + i             : fsw_mid_size(i-1) < degree <= fsw_mid_size(i), i < FSW_NUM_MID_BINS
+ *                                      (register path with the network of size fsw_mid_size(i), +inf padding)
+ *   bin FSW_BIN_LDS0 + i             : 256 << i < degree <= 512 << i, i < FSW_NUM_LDS_BINS (wave-sort path: the
+ *                                      neighbourhood is transposed through LDS, every wavefront sorts one slice's
+ *                                      line held across its lanes' registers)
+ *   bin FSW_BIN_GLOBAL               : degree > FSW_LDS_MAX_DEG (global-scratch bitonic path)
+ * General (non-unit) weights carry a weight next to every key, so their per-lane register path ends at
+ * FSW_MID_MAX_DEG_WEIGHTED and the bins above it run on the wave-sort path.                            */
 #define FSW_REG_MAX_DEG 32
+#define FSW_NUM_MID_BINS 9
+#define FSW_MID_SIZES {40, 48, 64, 80, 96, 128, 160, 192, 256}
+#define FSW_MID_MAX_DEG 256
+#define FSW_MID_MAX_DEG_WEIGHTED 128
 #define FSW_LDS_MAX_DEG 2048
-#define FSW_BIN_LDS (FSW_REG_MAX_DEG + 1)
-#define FSW_BIN_GLOBAL (FSW_REG_MAX_DEG + 2)
-#define FSW_NUM_BINS (FSW_REG_MAX_DEG + 3)
+#define FSW_BIN_MID0 (FSW_REG_MAX_DEG + 1)
+#define FSW_NUM_LDS_BINS 3
+#define FSW_BIN_LDS0 (FSW_BIN_MID0 + FSW_NUM_MID_BINS)
+#define FSW_BIN_GLOBAL (FSW_BIN_LDS0 + FSW_NUM_LDS_BINS)
+#define FSW_NUM_BINS (FSW_BIN_GLOBAL + 1)
 
 /* stats[] words written by fsw_graph_build / fsw_project_f32 (device int32[FSW_NUM_STATS]) */
 #define FSW_STAT_FLAGS 0        /* OR of FSW_FLAG_* */
 #define FSW_STAT_MAX_DEGREE 1
 #define FSW_STAT_NUM_ZERO_DEG 2
 #define FSW_STAT_NUM_REG 3      /* rows with 1 <= degree <= FSW_REG_MAX_DEG */
-#define FSW_STAT_NUM_LDS 4
+#define FSW_STAT_NUM_LDS 4      /* rows with FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (mid bins + LDS bin) */
 #define FSW_STAT_NUM_GLOBAL 5
 #define FSW_STAT_NNZ 6          /* fsw_graph_build_coalesced: number of CSR entries after coalescing */
 #define FSW_NUM_STATS 8

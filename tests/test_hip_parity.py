@@ -247,6 +247,104 @@ def test_long_rows_weighted_and_global_scratch_path(dev):
         assert relerr(out.cpu().numpy(), ref) < TOL
 
 
+def test_mid_degree_rows_every_padded_network_size(dev):
+    """Rows of in-degree 33..300: both ends of every padded register-path bin (csrc/embed_mid.hip, FSW_MID_SIZES), one
+    row past the last bin on the LDS path; unit weights, general weights (incl. a mass-deficient row that receives the
+    reference's pad element, and the weighted bins above 128 that stay on the LDS path), S not a multiple of 64, a zero
+    frequency, bias and total-mass column."""
+    from fsw_gnn_amd import build_csr, _lib
+    rng = np.random.default_rng(21)
+    sizes = [33, 40, 41, 48, 49, 64, 65, 80, 81, 96, 97, 128, 129, 160, 161, 192, 193, 255, 256, 257, 300, 35, 100]
+    assert set(_lib.MID_SIZES) <= set(sizes)
+    nrows, n, d, S = len(sizes), 600, 12, 70
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=85)
+    fr = cases.random_freqs(S, seed=86)
+    fr[5] = 0.0
+    bias = rng.standard_normal(S + 1).astype(np.float32)
+    rec = np.repeat(np.arange(nrows), sizes).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
+    order = rng.permutation(rec.size)                           # edge list in random order: the build groups it
+    w = (rng.random(rec.size) + 0.1).astype(np.float32)
+    w[rec == 2] *= 0.4 / w[rec == 2].sum()                      # row 2: total mass 0.4 < tau = 1 -> pad element carries 0.6
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    for weights in (None, w):
+        E = make_embedding(dev, V, fr, bias=bias, scale=0.7, encode_total_mass=True)
+        with torch.no_grad():
+            graph = build_csr(t(rec[order], dev, torch.int64), t(snd[order], dev, torch.int64),
+                              None if weights is None else t(weights[order], dev), nrows, n)
+            out = torch.empty((nrows, S + 1), device=dev)
+            E.embed_into(t(X, dev), graph, out)
+        st = graph.stats()
+        assert st[_lib.STAT_NUM_LDS] == nrows and st[_lib.STAT_NUM_REG] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0
+        bs = graph.bin_start.cpu().numpy()
+        assert bs[_lib.NUM_BINS] == nrows and bs[_lib.REG_MAX_DEG + 1] == 0
+        assert np.diff(bs)[_lib.REG_MAX_DEG + 1:].tolist() == [3, 2, 2, 2, 2, 3, 2, 2, 3, 2, 0, 0, 0]   # rows per mid bin, three LDS bins, global
+        ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if weights is None else weights.astype(np.float64), V, fr,
+                                      bias=bias, encode_total_mass=True, total_mass_encoding_scale=0.7)
+        assert relerr(out.cpu().numpy(), ref) < TOL
+        assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_wave_sort_rows_every_size_class(dev):
+    """Rows of 257..2048 neighbours at both ends of the three wave-sort classes (csrc/embed_wsort.hip: a wave holds a
+    slice's line in registers, 8 / 16 / 32 keys per lane), unit and general weights (one size class up for the pad
+    element; row 0 is mass-deficient), S not a multiple of the slice-group size, a zero frequency."""
+    from fsw_gnn_amd import build_csr, _lib
+    rng = np.random.default_rng(23)
+    sizes = [257, 512, 513, 1024, 1025, 2048, 600]
+    nrows, n, d, S = len(sizes), 2300, 8, 21
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=89)
+    fr = cases.random_freqs(S, seed=90)
+    fr[3] = 0.0
+    rec = np.repeat(np.arange(nrows), sizes).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
+    w = (rng.random(rec.size) + 0.1).astype(np.float32)
+    w[rec == 0] *= 0.3 / w[rec == 0].sum()
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    for weights in (None, w):
+        E = make_embedding(dev, V, fr, enable_bias=False, encode_total_mass=True)
+        with torch.no_grad():
+            graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), nrows, n)
+            out = torch.empty((nrows, S + 1), device=dev)
+            E.embed_into(t(X, dev), graph, out)
+        bs = np.diff(graph.bin_start.cpu().numpy())
+        assert bs[-4:].tolist() == [2, 3, 2, 0] and bs[:-4].sum() == 0
+        ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if weights is None else weights.astype(np.float64), V, fr,
+                                      encode_total_mass=True)
+        assert relerr(out.cpu().numpy(), ref) < TOL
+        assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_mid_degree_rows_backward(dev):
+    """Gradients through rows of 33..256 neighbours (forward on the padded register path, backward on the long-row kernels)."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(22)
+    sizes = [33, 64, 100, 129, 200, 256]
+    nrows, n, d, S = len(sizes), 400, 10, 24
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=87)
+    fr = cases.random_freqs(S, seed=88)
+    rec = np.repeat(np.arange(nrows), sizes).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
+    wts = (rng.random(rec.size) + 0.1).astype(np.float32)
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    R = rng.standard_normal((nrows, S))
+    for weights in (None, wts):
+        E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+        Xd = t(X, dev).requires_grad_(True)
+        graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), nrows, n)
+        out = E.embed_autograd(Xd, graph)
+        (out * t(R, dev)).sum().backward()
+        wv = np.ones(rec.size) if weights is None else weights.astype(np.float64)
+        gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, snd, wv, V, fr, R, Xp_override=_hip_projection(E, Xd))
+        assert relerr(out.detach().cpu().numpy(), O.fsw_embedding_forward(X, rowptr, snd, wv, V, fr)) < TOL
+        assert relerr(Xd.grad.cpu().numpy(), gX) < 2e-5
+        assert relerr(E.projVecs.grad.cpu().numpy(), gV) < 2e-5
+        assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
+
+
 def test_readout_layer(dev):
     from fsw_gnn_amd import FSW_readout
     rng = np.random.default_rng(4)
