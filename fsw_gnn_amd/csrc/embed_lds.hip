@@ -451,25 +451,4 @@ size_t embed_global_scratch_bytes(int64_t max_degree) {
   return embed_global_scratch_per_wg(max_degree) * kGlobalWgs * kSplitY;
 }
 
-int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
-  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
-  // the caller sized the scratch with fsw_embed_scratch_bytes(max_degree): kGlobalWgs * kSplitY equal parts
-  const int64_t per_wg = (int64_t)(a.scratch_bytes / (kGlobalWgs * kSplitY));
-  FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for the global path");
-  FSW_REQUIRE(per_wg >= (int64_t)embed_global_scratch_per_wg(a.max_degree),
-              "fsw_embed_f32: scratch buffer too small for the global path (need fsw_embed_scratch_bytes(max_degree))");
-  dim3 grid((unsigned)std::min<int64_t>(rows_upper, kGlobalWgs), kSplitY);
-  char* scratch = reinterpret_cast<char*>(a.scratch);
-  if (unit_fast)
-    k_embed_long<false, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
-                                                           a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                           a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL);
-  else
-    k_embed_long<true, true><<<grid, 256, 1024, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
-                                                          a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-                                                          a.mass_scale, scratch, per_wg, a.efeat, a.Ve, a.ldve, a.d_edge, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL);
-  FSW_LAUNCH_CHECK();
-  return 0;
-}
-
 }  // namespace fsw

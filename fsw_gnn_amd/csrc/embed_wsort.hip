@@ -128,6 +128,16 @@ struct WaveLine {
       merge_levels<LANES * 2>(lane);
     }
   }
+  // the 64 M elements form a bitonic sequence whose halves were already separated: finish the merge
+  __device__ __forceinline__ void merge_chunk() {
+    const int lane = lane_id();
+    half_cleaners<(kWave >> 1)>(lane);
+#pragma unroll
+    for (int st = M >> 1; st >= 1; st >>= 1)
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if ((j & st) == 0) cx(j, j + st);
+  }
   template <int ST>
   __device__ __forceinline__ void half_cleaners(int lane) {
     if constexpr (ST >= 1) {
@@ -185,20 +195,31 @@ __global__ void __launch_bounds__(256) k_embed_wsort(const int32_t* __restrict__
     const int ngroups = (S + SC - 1) / SC;
     for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
       const int k0 = g * SC;
-      // 1. gather + transpose: consecutive threads take consecutive slices of one neighbour
-      for (int i = threadIdx.x; i < Dtot * SC; i += blockDim.x) {
-        const int kk = i % SC, t = i / SC;
-        float key = 0.f;                                 // t == D (weighted): the reference's pad element at x = 0
-        if (t < D) {
-          const int kcl = min(k0 + kk, S - 1);
-          key = Xp[(int64_t)col[start + t] * ldp + kcl];
-          if (efeat) {   // edge features: + <e_ij, v_k[d_in:]> (reference fsw_embedding.py:934-968)
-            const float* er = efeat + (int64_t)(start + t) * d_edge;
-            const float* vr = Ve + (int64_t)kcl * ldve;
-            for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+      // 1. gather + transpose: consecutive threads take consecutive slices of one neighbour.  kGatherDepth loads are
+      //    issued before the first LDS store: the loop is otherwise one HBM round trip per iteration.
+      constexpr int kGatherDepth = 8;
+      const int total = Dtot * SC;
+      for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * kGatherDepth) {
+        float key[kGatherDepth];
+        int pos[kGatherDepth];
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) {
+          const int i = min(i0 + u * (int)blockDim.x, total - 1);   // clamped: the tail re-reads the last element
+          const int kk = i % SC, t = i / SC;
+          pos[u] = kk * LINE + t + t / M;
+          key[u] = 0.f;                                  // t == D (weighted): the reference's pad element at x = 0
+          if (t < D) {
+            const int kcl = min(k0 + kk, S - 1);
+            key[u] = Xp[(int64_t)col[start + t] * ldp + kcl];
+            if (efeat) {   // edge features: + <e_ij, v_k[d_in:]> (reference fsw_embedding.py:934-968)
+              const float* er = efeat + (int64_t)(start + t) * d_edge;
+              const float* vr = Ve + (int64_t)kcl * ldve;
+              for (int q = 0; q < d_edge; ++q) key[u] = fmaf(er[q], vr[q], key[u]);
+            }
           }
         }
-        tile[kk * LINE + t + t / M] = key;
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) tile[pos[u]] = key[u];   // clamped duplicates store the same value
       }
       __syncthreads();
       // 2 + 3. one wave per line
@@ -268,6 +289,228 @@ __global__ void __launch_bounds__(256) k_embed_wsort(const int32_t* __restrict__
     if (has_mass && blockIdx.y == 0 && threadIdx.x == 0)
       out[(int64_t)node * ldo] = out_scale * (mass_encode_w((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
   }
+}
+
+// ---- rows above FSW_LDS_MAX_DEG: one wavefront per (row, slice) line, the line in a global scratch buffer --------------
+// The line is sorted in chunks of 64 M elements in registers (WaveLine::sort), then merged bitonically: the exchanges
+// at distances >= one chunk are element-wise min/max sweeps over the scratch line (coalesced, kSweepDepth pairs in flight
+// per lane), the rest of every merge level happens in registers again (WaveLine::merge_chunk); the last level feeds the
+// readout instead of going back to memory.  Any in-degree works; the scratch holds 4 (unit) or 8 bytes per element of the
+// padded line and wave.  The gather is one 4-byte read per neighbour and slice here (the four waves of a workgroup take
+// adjacent slices, so they share sectors): these rows are few.
+constexpr int kSweepDepth = 4;
+
+template <bool WEIGHTED>
+__device__ __forceinline__ void sweep_pairs(float* __restrict__ sk, float* __restrict__ sw, int Dp, int size, int st, bool flip) {
+  // pairs (i, p): flip: i in the lower half of every block of `size`, p = its mirror image in the block;
+  //               otherwise i and i + st inside blocks of 2 st
+  const int npairs = Dp >> 1;
+  const int half = size >> 1;
+  for (int i0 = lane_id(); i0 < npairs; i0 += kWave * kSweepDepth) {   // npairs is a multiple of 64 * kSweepDepth
+    int ia[kSweepDepth], ib[kSweepDepth];
+    float ka[kSweepDepth], kb[kSweepDepth], wa[kSweepDepth], wb[kSweepDepth];
+#pragma unroll
+    for (int u = 0; u < kSweepDepth; ++u) {
+      const int idx = i0 + u * kWave;
+      if (flip) {
+        const int blk = idx / half, off = idx - blk * half;
+        ia[u] = blk * size + off;
+        ib[u] = blk * size + size - 1 - off;
+      } else {
+        const int blk = idx / st, off = idx - blk * st;
+        ia[u] = blk * 2 * st + off;
+        ib[u] = ia[u] + st;
+      }
+      ka[u] = sk[ia[u]];
+      kb[u] = sk[ib[u]];
+      if constexpr (WEIGHTED) {
+        wa[u] = sw[ia[u]];
+        wb[u] = sw[ib[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSweepDepth; ++u) {
+      if constexpr (WEIGHTED) {
+        if (kb[u] < ka[u]) {
+          sk[ia[u]] = kb[u];
+          sk[ib[u]] = ka[u];
+          sw[ia[u]] = wb[u];
+          sw[ib[u]] = wa[u];
+        }
+      } else {
+        sk[ia[u]] = fminf(ka[u], kb[u]);
+        sk[ib[u]] = fmaxf(ka[u], kb[u]);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the next sweep reads what other lanes of this wave wrote
+}
+
+template <int M, bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
+                                                            int64_t ldp, int S, const float* __restrict__ freqs, float tau,
+                                                            float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
+                                                            float out_scale, int has_mass, int mass_fn, float mass_scale,
+                                                            const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                            int64_t ldve, int d_edge, char* __restrict__ scratch, int64_t wave_bytes) {
+  constexpr int CAP = M * kWave;
+  const int lane = lane_id();
+  const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
+  float* sk = reinterpret_cast<float*>(scratch + (int64_t)gw * wave_bytes);
+  float* sw = sk + (wave_bytes >> 3);                   // second half of the wave's region (weighted only)
+  const int pbeg = bin_start[FSW_BIN_GLOBAL], pend = bin_start[FSW_BIN_GLOBAL + 1];
+  const int64_t nlines = (int64_t)(pend - pbeg) * S;
+  for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
+    const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int Dtot = WEIGHTED ? D + 1 : D;
+    const int Dp = (int)pow2ceil((uint32_t)Dtot);       // >= 2 CAP: D > FSW_LDS_MAX_DEG = CAP
+    double m = (double)D;
+    float padw = 0.f;
+    if constexpr (WEIGHTED) {
+      double part = 0.0;
+      for (int t = lane; t < D; t += kWave) part += (double)(w ? w[start + t] : 1.f);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      m = part;
+      padw = (float)fmax((double)tau - m, 0.0);
+    }
+    const double inv = 1.0 / (WEIGHTED ? fmax(m, (double)tau) : m);
+    const float xif = freqs[k];
+    const double xi = (double)xif;
+    const bool lin = xif < 1e-30f;
+    // A. chunks: gather, sort in registers, park in the scratch line
+    for (int c0 = 0; c0 < Dp; c0 += CAP) {
+      WaveLine<M, WEIGHTED> ln;
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int t = c0 + lane * M + j;
+        float key = __builtin_inff(), wt = 0.f;
+        if (t < D) {
+          key = Xp[(int64_t)col[start + t] * ldp + k];
+          if (efeat) {   // edge features: + <e_ij, v_k[d_in:]> (reference fsw_embedding.py:934-968)
+            const float* er = efeat + (int64_t)(start + t) * d_edge;
+            const float* vr = Ve + (int64_t)k * ldve;
+            for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+          }
+          if constexpr (WEIGHTED) wt = w ? w[start + t] : 1.f;
+        } else if (WEIGHTED && t == D) {
+          key = 0.f;                                    // the reference's pad element at x = 0
+          wt = padw;
+        }
+        ln.k[j] = key;
+        if constexpr (WEIGHTED) ln.w[j] = wt;
+      }
+      ln.sort();
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        sk[c0 + lane * M + j] = ln.k[j];
+        if constexpr (WEIGHTED) sw[c0 + lane * M + j] = ln.w[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    // B. merge levels
+    float acc = 0.f;
+    double carry = 0.0;                                 // cumulative weight before the current chunk (weighted readout)
+    double sd = 0.0, cd = 1.0;
+    const double step = xi * inv;                       // revolutions per rank (unit weights)
+    if (!WEIGHTED && !lin) sincospi(2.0 * (step - rint(step)), &sd, &cd);
+    for (int size = 2 * CAP; size <= Dp; size <<= 1) {
+      sweep_pairs<WEIGHTED>(sk, sw, Dp, size, 0, true);
+      for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs<WEIGHTED>(sk, sw, Dp, size, st, false);
+      const bool last = size == Dp;
+      for (int c0 = 0; c0 < Dp; c0 += CAP) {
+        if (last && c0 >= Dtot) break;                  // only +inf padding from here on
+        WaveLine<M, WEIGHTED> ln;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          ln.k[j] = sk[c0 + lane * M + j];
+          if constexpr (WEIGHTED) ln.w[j] = sw[c0 + lane * M + j];
+        }
+        ln.merge_chunk();
+        if (!last) {
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            sk[c0 + lane * M + j] = ln.k[j];
+            if constexpr (WEIGHTED) sw[c0 + lane * M + j] = ln.w[j];
+          }
+          continue;
+        }
+        // readout of ranks c0 + lane*M + j
+        const int r0 = c0 + lane * M;
+        if constexpr (!WEIGHTED) {
+          if (lin) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
+          } else {
+            double s, c;
+            const double x0 = step * (double)r0;
+            sincospi(2.0 * (x0 - rint(x0)), &s, &c);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+              const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
+              acc += (r0 + j < D) ? (float)(sn - s) * ln.k[j] : 0.f;
+              s = sn;
+              c = cn;
+            }
+          }
+        } else {
+          double part = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) part += (double)ln.w[j];
+          double c = carry + wave_exclusive_scan_f64(part);
+          double tot = part;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+          carry += tot;
+          float sprev = lin ? 0.f : sin2pi_rev_w(xi * (c * inv));
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            const bool valid = r0 + j < Dtot;
+            c += (double)ln.w[j];
+            if (lin) {
+              acc += valid ? ln.w[j] * ln.k[j] : 0.f;
+            } else {
+              const float s = sin2pi_rev_w(xi * (c * inv));
+              acc += valid ? (s - sprev) * ln.k[j] : 0.f;
+              sprev = s;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+    acc = wave_sum_w(acc) * (lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiW * xi)));
+    if (lane == 0) {
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (acc + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_w((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
+int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  if (rows_upper <= 0) return 0;
+  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
+  FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
+  const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
+  const int64_t wave_bytes = Dp * 8;
+  int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
+  nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 4) * 4) & ~(int64_t)3;
+  FSW_REQUIRE(nwaves >= 4, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
+  char* scratch = reinterpret_cast<char*>(a.scratch);
+  if (unit_fast)
+    k_embed_wsort_global<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
+        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes);
+  else
+    k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
+        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes);
+  FSW_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int M, bool WEIGHTED>
