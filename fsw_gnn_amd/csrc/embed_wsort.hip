@@ -17,6 +17,7 @@
 //                cumsum of fsw_embedding.py:1031-1032), phase in float64, the reference's pad element
 //                (fsw_embedding.py:787-821) is element D.
 #include <algorithm>
+#include <type_traits>
 #include "fsw_common.h"
 #include "sortnet.h"
 
@@ -53,6 +54,26 @@ __device__ __forceinline__ double wave_exclusive_scan_f64(double v) {
   return inc - v;
 }
 
+// value of lane ^ MASK.  Distances inside a row of 16 lanes go through DPP (VALU rate, no LDS crossbar): xor 1, 2, 3 are
+// quad permutes, xor 7 / 15 the half-row / row mirrors, xor 4 = mirror7 o quad3, xor 8 = mirror15 o mirror7; xor 16 and 31
+// are ds_swizzle bit-mode patterns (inside 32 lanes); only 32 and 63 need ds_bpermute.
+template <int MASK>
+__device__ __forceinline__ float xor_lane(float v) {
+  const int x = __float_as_int(v);
+  auto dpp = [](int y, auto ctrl) { return __builtin_amdgcn_update_dpp(0, y, decltype(ctrl)::value, 0xF, 0xF, true); };
+  using std::integral_constant;
+  if constexpr (MASK == 1) return __int_as_float(dpp(x, integral_constant<int, 0xB1>{}));
+  else if constexpr (MASK == 2) return __int_as_float(dpp(x, integral_constant<int, 0x4E>{}));
+  else if constexpr (MASK == 3) return __int_as_float(dpp(x, integral_constant<int, 0x1B>{}));
+  else if constexpr (MASK == 7) return __int_as_float(dpp(x, integral_constant<int, 0x141>{}));
+  else if constexpr (MASK == 15) return __int_as_float(dpp(x, integral_constant<int, 0x140>{}));
+  else if constexpr (MASK == 4) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x141>{}), integral_constant<int, 0x1B>{}));
+  else if constexpr (MASK == 8) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x140>{}), integral_constant<int, 0x141>{}));
+  else if constexpr (MASK == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401F));
+  else if constexpr (MASK == 31) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x7C1F));
+  else return __shfl_xor(v, MASK);
+}
+
 // keys (and weights) of one line across the wave, blocked layout; ascending over element index l*M + j afterwards
 template <int M, bool WEIGHTED>
 struct WaveLine {
@@ -60,13 +81,13 @@ struct WaveLine {
   float w[WEIGHTED ? M : 1];
 
   // exchange with another lane: this lane keeps the smaller (lower == true) or the larger key of each pair
-  template <int JREV>
-  __device__ __forceinline__ void exchange(int mask, bool lower) {
+  template <int JREV, int MASK>
+  __device__ __forceinline__ void exchange(bool lower) {
     float ok[M], ow[WEIGHTED ? M : 1];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      ok[j] = __shfl_xor(k[JREV ? M - 1 - j : j], mask);
-      if constexpr (WEIGHTED) ow[j] = __shfl_xor(w[JREV ? M - 1 - j : j], mask);
+      ok[j] = xor_lane<MASK>(k[JREV ? M - 1 - j : j]);
+      if constexpr (WEIGHTED) ow[j] = xor_lane<MASK>(w[JREV ? M - 1 - j : j]);
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -118,7 +139,7 @@ struct WaveLine {
   template <int LANES>
   __device__ __forceinline__ void merge_levels(int lane) {
     if constexpr (LANES <= kWave) {
-      exchange<1>(LANES - 1, (lane & (LANES >> 1)) == 0);          // element i against i ^ (LANES*M - 1)
+      exchange<1, LANES - 1>((lane & (LANES >> 1)) == 0);          // element i against i ^ (LANES*M - 1)
       half_cleaners<(LANES >> 2)>(lane);
 #pragma unroll
       for (int st = M >> 1; st >= 1; st >>= 1)
@@ -141,7 +162,7 @@ struct WaveLine {
   template <int ST>
   __device__ __forceinline__ void half_cleaners(int lane) {
     if constexpr (ST >= 1) {
-      exchange<0>(ST, (lane & ST) == 0);
+      exchange<0, ST>((lane & ST) == 0);
       half_cleaners<(ST >> 1)>(lane);
     }
   }
