@@ -1,20 +1,16 @@
-// Fused neighbourhood kernels for long rows: LDS bitonic path (FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG)
-// and global-scratch bitonic path (degree > FSW_LDS_MAX_DEG).  gfx950.
+// Backward kernels for long rows (in-degree above FSW_REG_MAX_DEG): LDS bitonic variant up to FSW_LDS_MAX_DEG and
+// global-scratch bitonic variant above.  gfx950.  (The forward of these rows lives in embed_mid.hip / embed_wsort.hip.)
 //
 // One workgroup takes one recipient row and walks its slices in groups of SC.  Per group:
 //   1. gather   Xp[col_t, k0 .. k0+SC-1] for every neighbour t (row segments of SC floats, coalesced along
-//               the slice axis) and store them transposed, tile[slice][t], one padded line per slice;
+//               the slice axis) and store them transposed, tile[slice][t], one padded line per slice, as 64-bit
+//               (orderable key bits << 32 | element index) words;
 //   2. sort     every slice's line with a bitonic network (all 256 threads share each stage; padding
-//               elements carry +inf keys).  This is the per-neighbourhood sort that the reference obtains
-//               from a global per-slice sort plus two E*S int64 key sorts (fsw_embedding.py:923, 2586-2678,
-//               2721-2758);
-//   3. readout  one wave per slice: cumulative weights by wave scans (the segmented cumsum of
-//               fsw_embedding.py:1031-1032), phase in float64, Delta_t = [sin(2 pi xi c_t) -
-//               sin(2 pi xi c_{t-1})] (1+xi)/(pi xi) (= fsw_embedding.py:1047-1075 by sum-to-product), reduce.
-// Unit weights with tau <= 1 sort bare float keys (c_t = (t+1)/D needs no payload).  General weights sort
-// 64-bit (orderable key bits << 32 | element index) words; the element index fetches the weight, and the
-// reference's pad element (x = 0, weight max(tau - m, 0), fsw_embedding.py:787-821) is always element D.
-// The global path runs the same code on a tile in a global scratch buffer instead of LDS.
+//               elements carry +inf keys);
+//   3. walk     one wave per slice over the sorted line: cumulative weight by wave scans, coefficient and its
+//               xi-derivative in float64, contributions scattered back to element order, then slice-contiguous
+//               atomics into gXp.
+// The global variant runs the same code on a tile in a global scratch buffer instead of LDS.
 #include <algorithm>
 #include "fsw_common.h"
 
@@ -112,147 +108,6 @@ __device__ __forceinline__ void bitonic_lines(T* tile, int nlines, int Dp, int l
       }
       __syncthreads();
     }
-  }
-}
-
-template <bool WEIGHTED, bool GLOBAL>
-__global__ void __launch_bounds__(256) k_embed_long(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                    const float* __restrict__ w, const int32_t* __restrict__ perm,
-                                                    const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
-                                                    int64_t ldp, int S, const float* __restrict__ freqs, float tau,
-                                                    float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
-                                                    float out_scale, int has_mass, int mass_fn, float mass_scale,
-                                                    char* __restrict__ scratch, int64_t scratch_per_wg,
-                                                    const float* __restrict__ efeat, const float* __restrict__ Ve, int64_t ldve,
-                                                    int d_edge, int bin_lo, int bin_hi) {
-  using E = Elem<WEIGHTED>;
-  using T = typename E::type;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS carve: [result floats: 64][row weights: kLdsWeightFloats (weighted LDS variant)][tile]
-  float* res = reinterpret_cast<float*>(smem);
-  float* wrow = res + 64;
-  T* tile;
-  int tile_bytes;
-  if constexpr (GLOBAL) {
-    tile = reinterpret_cast<T*>(scratch + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * scratch_per_wg);
-    tile_bytes = 0;
-  } else {
-    constexpr int head = (64 + (WEIGHTED ? kLdsWeightFloats : 0)) * 4;
-    tile = reinterpret_cast<T*>(smem + head);
-    tile_bytes = kLdsBytes - head;
-  }
-  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];   // rows of the degree bins bin_lo .. bin_hi
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
-
-  for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
-    const int node = perm[p];
-    const int start = rowptr[node];
-    const int D = rowptr[node + 1] - start;
-    const int Dtot = WEIGHTED ? D + 1 : D;  // the weighted variant always carries the pad element
-    const int Dp = (int)pow2ceil((uint32_t)Dtot);
-    const int ls = Dp + 1;  // padded line: conflict-free transposed stores
-    int SC;
-    if constexpr (GLOBAL) {
-      SC = kGlobalSC;
-    } else {
-      SC = 64;
-      while (SC > 1 && (int64_t)SC * ls * (int)sizeof(T) > tile_bytes) SC >>= 1;
-    }
-
-    // row mass in float64 (uniform over the workgroup) and, on the global path, weights are re-read
-    double m = 0.0;
-    if constexpr (WEIGHTED) {
-      __shared__ double msum[4];
-      double part = 0.0;
-      for (int t = threadIdx.x; t < D; t += blockDim.x) {
-        const float wt = w ? w[start + t] : 1.f;
-        if constexpr (!GLOBAL) wrow[t] = wt;
-        part += (double)wt;
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-      if (lane == 0) msum[wv] = part;
-      __syncthreads();
-      m = msum[0] + msum[1] + msum[2] + msum[3];
-      if constexpr (!GLOBAL)
-        if (threadIdx.x == 0) wrow[D] = (float)fmax((double)tau - m, 0.0);
-      __syncthreads();
-    } else {
-      m = (double)D;
-    }
-    const double denom = WEIGHTED ? fmax(m, (double)tau) : m;
-    const double inv = 1.0 / denom;
-    const float padw = WEIGHTED ? (float)fmax((double)tau - m, 0.0) : 0.f;
-
-    const int ngroups = (S + SC - 1) / SC;
-    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
-      const int k0 = g * SC;
-      // 1. gather + transpose
-      for (int i = threadIdx.x; i < Dp * SC; i += blockDim.x) {
-        const int kk = i % SC, t = i / SC;
-        T e = E::pad();
-        if (t < D) {
-          const int kcl = min(k0 + kk, S - 1);
-          e = E::make(long_key(Xp, ldp, col, start + t, kcl, efeat, Ve, ldve, d_edge), t);
-        } else if (WEIGHTED && t == D) {
-          e = E::make(0.f, t);  // pad element at x = 0
-        }
-        tile[(int64_t)kk * ls + t] = e;
-      }
-      __syncthreads();
-      // 2. sort every slice line
-      bitonic_lines<T>(tile, SC, Dp, ls);
-      // 3. readout, one wave per slice
-      for (int kk = wv; kk < SC; kk += 4) {
-        const int k = k0 + kk;
-        if (k >= S) break;
-        const float xif = freqs[k];
-        const double xi = (double)xif;
-        const bool lin = xif < 1e-30f;
-        const T* line = tile + (int64_t)kk * ls;
-        double carry = 0.0;
-        float s_carry = 0.f, acc = 0.f;
-        for (int t0 = 0; t0 < Dtot; t0 += kWave) {
-          const int t = t0 + lane;
-          const bool valid = t < Dtot;
-          const T e = valid ? line[t] : E::make(0.f, 0);
-          const float key = E::key(e);
-          double c;
-          float wt;
-          if constexpr (WEIGHTED) {
-            const int id = E::idx(e);
-            if constexpr (GLOBAL)
-              wt = valid ? (id == D ? padw : (w ? w[start + id] : 1.f)) : 0.f;
-            else
-              wt = valid ? wrow[id] : 0.f;
-            c = wave_inclusive_scan_f64((double)wt) + carry;
-          } else {
-            wt = 1.f;
-            c = (double)(t + 1);
-          }
-          if (lin) {
-            acc = valid ? fmaf(wt, key, acc) : acc;
-          } else {
-            const float s = sin2pi_rev_l(xi * (c * inv));
-            float sp = __shfl_up(s, 1);
-            if (lane == 0) sp = s_carry;
-            acc = valid ? fmaf(s - sp, key, acc) : acc;
-            s_carry = __shfl(s, kWave - 1);
-          }
-          carry = __shfl(c, kWave - 1);
-        }
-        acc = wave_sum_f32(acc);
-        if (lane == 0) {
-          const float scale = lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiL * xi));
-          res[kk] = out_scale * (scale * acc + (bias ? bias[has_mass + k] : 0.f));
-        }
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < SC && k0 + (int)threadIdx.x < S) out[(int64_t)node * ldo + has_mass + k0 + threadIdx.x] = res[threadIdx.x];
-      __syncthreads();
-    }
-    if (has_mass && blockIdx.y == 0 && threadIdx.x == 0)
-      out[(int64_t)node * ldo] = out_scale * (mass_encode_l((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
   }
 }
 
