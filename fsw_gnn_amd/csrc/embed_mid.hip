@@ -163,11 +163,15 @@ __global__ void __launch_bounds__(256) k_embed_mid_weighted(const int32_t* __res
   }
 }
 
-// rows_upper: upper bound of the rows in the mid bins (the per-bin counts stay on the device); surplus workgroups of
-// an instance whose bin is short or empty leave at once.
-int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper, hipStream_t stream) {
-  if (rows_upper <= 0) return 0;
-  dim3 grid((unsigned)std::min<int64_t>(rows_upper, 8192), (unsigned)ceil_div(a.S, 4 * kWave));
+// The instantiations are split over three translation units (FSW_MID_PART = 0, 1, 2; see the Makefile): the
+// 256-wire network alone takes minutes to compile.
+#ifndef FSW_MID_PART
+#error "compile with -DFSW_MID_PART=0|1|2"
+#endif
+int launch_mid_unit_small(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
+int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
+int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
+
 #define FSW_MID_UNIT(i, DP)                                                                                               \
   k_embed_mid_unit<DP><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S,  \
                                                  a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,       \
@@ -179,16 +183,38 @@ int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
                                                          a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve,      \
                                                          a.d_edge);                                                       \
   FSW_LAUNCH_CHECK()
-  if (unit_fast) {
-    FSW_MID_UNIT(0, 40); FSW_MID_UNIT(1, 48); FSW_MID_UNIT(2, 64); FSW_MID_UNIT(3, 80); FSW_MID_UNIT(4, 96);
-    FSW_MID_UNIT(5, 128); FSW_MID_UNIT(6, 160); FSW_MID_UNIT(7, 192); FSW_MID_UNIT(8, 256);
-  } else {   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the LDS path (embed_lds.hip)
-    FSW_MID_WEIGHTED(0, 40); FSW_MID_WEIGHTED(1, 48); FSW_MID_WEIGHTED(2, 64); FSW_MID_WEIGHTED(3, 80);
-    FSW_MID_WEIGHTED(4, 96); FSW_MID_WEIGHTED(5, 128);
-  }
-#undef FSW_MID_UNIT
-#undef FSW_MID_WEIGHTED
+
+#if FSW_MID_PART == 0
+int launch_mid_unit_small(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
+  FSW_MID_UNIT(0, 40); FSW_MID_UNIT(1, 48); FSW_MID_UNIT(2, 64); FSW_MID_UNIT(3, 80); FSW_MID_UNIT(4, 96); FSW_MID_UNIT(5, 128);
   return 0;
 }
+
+// rows_upper: upper bound of the rows in the mid bins (the per-bin counts stay on the device); surplus workgroups of
+// an instance whose bin is short or empty leave at once.
+int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper, hipStream_t stream) {
+  if (rows_upper <= 0) return 0;
+  dim3 grid((unsigned)std::min<int64_t>(rows_upper, 8192), (unsigned)ceil_div(a.S, 4 * kWave));
+  int rc;
+  if (unit_fast) {
+    if ((rc = launch_mid_unit_small(a, grid, stream))) return rc;
+    return launch_mid_unit_large(a, grid, stream);
+  }
+  return launch_mid_weighted(a, grid, stream);   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the wave-sort path (embed_wsort.hip)
+}
+#elif FSW_MID_PART == 1
+int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
+  FSW_MID_UNIT(6, 160); FSW_MID_UNIT(7, 192); FSW_MID_UNIT(8, 256);
+  return 0;
+}
+#else
+int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
+  FSW_MID_WEIGHTED(0, 40); FSW_MID_WEIGHTED(1, 48); FSW_MID_WEIGHTED(2, 64); FSW_MID_WEIGHTED(3, 80);
+  FSW_MID_WEIGHTED(4, 96); FSW_MID_WEIGHTED(5, 128);
+  return 0;
+}
+#endif
+#undef FSW_MID_UNIT
+#undef FSW_MID_WEIGHTED
 
 }  // namespace fsw
