@@ -1,0 +1,454 @@
+// Backward of the neighbourhood embedding for rows above FSW_REG_MAX_DEG, wave-sort form.  gfx950.
+//
+//   out[i, k] = sum_r C_k(r) x_(r)           ->   gXp[col_t, k] += g[i, k] C_k(rank_k(t)),
+//   C = F(c_r) - F(c_r - w_r)                      gfreq[k]     += g[i, k] sum_r dC/dxi x_(r)
+// with F(xi; c) = (1 + xi) sin(2 pi xi c)/(pi xi) (reference
+// fsw_embedding.py:1047-1109 differentiated by hand, verified against the reference's autograd in
+// tests/test_hip_parity.py).  Same structure as the forward (embed_wsort.hip): the neighbourhood transposed through
+// LDS, one wavefront per (row, slice) line held across its registers -- here every key carries its ELEMENT INDEX as
+// payload.  After the sort lane l owns ranks l*M..; it evaluates F and dF/dxi (unit weights: sin and cos of the
+// rank angle by a float64 rotation; general weights: cumulative weight by in-lane prefix + float64 wave scan, then
+// sincospi), reduces gfreq over the wave and drops g*C into the element's ORIGINAL position of the same LDS line.
+// After a barrier all threads add the tile to gXp with the lanes along the slice axis (runs of SC floats per
+// neighbour: the shape float atomics run fastest in), or store it to gkey (edge features).
+// Rows above FSW_LDS_MAX_DEG: one wave per line in a global scratch region, chunks sorted in registers and merged by
+// sweeps as in the forward; the contribution is scattered to element order inside the wave's scratch and then added
+// with one 4-byte atomic per neighbour (these rows are few).
+#include <algorithm>
+#include "fsw_common.h"
+#include "sortnet.h"
+#include "wave_sort.h"
+
+namespace fsw {
+
+constexpr double kPiB = 3.14159265358979323846;
+constexpr int kWbLdsBytes = 69 * 1024;
+constexpr int kWbSplitY = 4;
+
+__device__ __forceinline__ float wave_sum_b(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_b64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_exclusive_scan_b64(double v) {
+  double inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const double t = __shfl_up(inc, off);
+    if (lane_id() >= off) inc += t;
+  }
+  return inc - v;
+}
+
+// F and dF/dxi at normalised cumulative weight c, given sin and cos of 2 pi xi c; series for tiny phases (the two terms
+// of dF cancel there); xi == 0: F = 2 c, dF = 2 c.
+__device__ __forceinline__ void F_dF_sc(double xi, double c, double s, double co, double& F, double& dF) {
+  const double x = 2.0 * kPiB * xi * c;
+  if (x < 1e-4) {
+    const double q = 1.0 - x * x * (1.0 / 6.0);
+    F = (1.0 + xi) * 2.0 * c * q;
+    dF = 2.0 * c * q - (1.0 + xi) * 2.0 * c * (2.0 * kPiB * c) * (2.0 * kPiB * c) * xi * (1.0 / 3.0);
+  } else {
+    F = (1.0 + xi) * s / (kPiB * xi);
+    dF = -s / (kPiB * xi * xi) + (1.0 + xi) * 2.0 * c * co / xi;
+  }
+}
+__device__ __forceinline__ void F_dF(double xi, double c, double& F, double& dF) {
+  const double ph = xi * c;
+  double s, co;
+  sincospi(2.0 * (ph - rint(ph)), &s, &co);
+  F_dF_sc(xi, c, s, co, F, dF);
+}
+
+// Walks the sorted line held by `ln` (ranks r0 + j, j < M, of a line of Dtot elements of which the first D are
+// neighbours): calls emit(element index, g * C) for every neighbour and returns this lane's share of the slice's gfreq.
+// WEIGHTED: weight_of(index) returns the element's weight, `cbase` is the cumulative weight before this lane's first
+// element on entry (only used when WEIGHTED).
+template <int M, bool WEIGHTED, class WeightFn, class EmitFn>
+__device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, int r0, int D, int Dtot, double xi, double inv, float gi,
+                                           double cbase, WeightFn weight_of, EmitFn emit) {
+  float gf = 0.f;
+  double Fp, dFp;
+  if constexpr (!WEIGHTED) {
+    const double step = xi * inv;   // revolutions per rank
+    double sd, cd, s, c;
+    sincospi(2.0 * (step - rint(step)), &sd, &cd);
+    const double x0 = step * (double)r0;
+    sincospi(2.0 * (x0 - rint(x0)), &s, &c);
+    F_dF_sc(xi, (double)r0 * inv, s, c, Fp, dFp);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
+      s = sn;
+      c = cn;
+      double F, dF;
+      F_dF_sc(xi, (double)min(r0 + j + 1, D) * inv, s, c, F, dF);
+      if (r0 + j < D) {
+        emit(__float_as_int(ln.w[j]), gi * (float)(F - Fp));
+        gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
+      }
+      Fp = F;
+      dFp = dF;
+    }
+  } else {
+    double c = cbase;
+    F_dF(xi, c * inv, Fp, dFp);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int id = __float_as_int(ln.w[j]);
+      const bool valid = r0 + j < Dtot;
+      c += valid ? (double)weight_of(id) : 0.0;
+      double F, dF;
+      F_dF(xi, c * inv, F, dF);
+      if (valid) {
+        if (id < D) emit(id, gi * (float)(F - Fp));   // the pad element (id == D) has no source row
+        gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
+      }
+      Fp = F;
+      dFp = dF;
+    }
+  }
+  return gf;
+}
+
+template <int M, bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                         const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi,
+                                                         const float* __restrict__ Xp, int64_t ldp, int S,
+                                                         const float* __restrict__ freqs, float tau, const float* __restrict__ g,
+                                                         int64_t ldg, int gcol0, float out_scale, float* __restrict__ gXp,
+                                                         int64_t ldgp, float* __restrict__ gfreq, const float* __restrict__ efeat,
+                                                         const float* __restrict__ Ve, int64_t ldve, int d_edge,
+                                                         float* __restrict__ gkey, int64_t ldk) {
+  constexpr int CAP = M * kWave;
+  constexpr int LINE = CAP + kWave + 1;   // one pad per M elements, odd stride
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wrow = smem;                                   // [LINE] weights of the row, padded like a line (weighted only)
+  float* tile = smem + (WEIGHTED ? LINE : 0);           // [SC][LINE]
+  constexpr int kTileLines = (kWbLdsBytes / 4 - (WEIGHTED ? LINE : 0)) / LINE;
+  static_assert(kTileLines >= 1, "a line must fit the LDS budget");
+  constexpr int SC = kTileLines >= 64 ? 64 : (kTileLines >= 4 ? (kTileLines & ~3) : kTileLines);
+  __shared__ double msum[4];
+  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];
+  const int lane = lane_id(), wv = wave_id();
+
+  for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int Dtot = WEIGHTED ? D + 1 : D;
+    double m = (double)D;
+    if constexpr (WEIGHTED) {
+      double part = 0.0;
+      for (int t = threadIdx.x; t < D; t += blockDim.x) {
+        const float wt = w ? w[start + t] : 1.f;
+        wrow[t + t / M] = wt;
+        part += (double)wt;
+      }
+      part = wave_sum_b64(part);
+      if (lane == 0) msum[wv] = part;
+      __syncthreads();
+      m = msum[0] + msum[1] + msum[2] + msum[3];
+      if (threadIdx.x == 0) wrow[D + D / M] = (float)fmax((double)tau - m, 0.0);
+      __syncthreads();
+    }
+    const double inv = 1.0 / (WEIGHTED ? fmax(m, (double)tau) : m);
+
+    const int ngroups = (S + SC - 1) / SC;
+    for (int grp = blockIdx.y; grp < ngroups; grp += gridDim.y) {
+      const int k0 = grp * SC;
+      constexpr int kGatherDepth = 8;
+      const int total = Dtot * SC;
+      for (int i0 = threadIdx.x; i0 < total; i0 += blockDim.x * kGatherDepth) {
+        float key[kGatherDepth];
+        int pos[kGatherDepth];
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) {
+          const int i = min(i0 + u * (int)blockDim.x, total - 1);
+          const int kk = i % SC, t = i / SC;
+          pos[u] = kk * LINE + t + t / M;
+          key[u] = 0.f;                                  // t == D (weighted): the reference's pad element at x = 0
+          if (t < D) {
+            const int kcl = min(k0 + kk, S - 1);
+            key[u] = Xp[(int64_t)col[start + t] * ldp + kcl];
+            if (efeat) {
+              const float* er = efeat + (int64_t)(start + t) * d_edge;
+              const float* vr = Ve + (int64_t)kcl * ldve;
+              for (int q = 0; q < d_edge; ++q) key[u] = fmaf(er[q], vr[q], key[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherDepth; ++u) tile[pos[u]] = key[u];
+      }
+      __syncthreads();
+      for (int kk = wv; kk < SC; kk += 4) {
+        const int k = k0 + kk;
+        if (k >= S) break;
+        WaveLine<M, true, true> ln;
+        float* line = tile + kk * LINE;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const int t = lane * M + j;
+          ln.k[j] = t < Dtot ? line[lane * (M + 1) + j] : __builtin_inff();
+          ln.w[j] = __int_as_float(t);
+        }
+        ln.sort();
+        const double xi = (double)freqs[k];
+        const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
+        double cbase = 0.0;
+        if constexpr (WEIGHTED) {
+          double part = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            const int id = __float_as_int(ln.w[j]);
+            part += (lane * M + j < Dtot) ? (double)wrow[id + id / M] : 0.0;
+          }
+          cbase = wave_exclusive_scan_b64(part);
+        }
+        float gf = walk_line<M, WEIGHTED>(
+            ln, lane * M, D, Dtot, xi, inv, gi, cbase, [&](int id) { return wrow[id + id / M]; },
+            [&](int id, float v) { line[id + id / M] = v; });   // every lane has read its keys: the line is free
+        gf = wave_sum_b(gf);
+        if (lane == 0 && gfreq) atomicAdd(gfreq + k, gf);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < D * SC; i += blockDim.x) {
+        const int kk = i % SC, t = i / SC;
+        if (k0 + kk < S) {
+          const float v = tile[kk * LINE + t + t / M];
+          if (gkey) gkey[(int64_t)(start + t) * ldk + k0 + kk] = v;   // edge features: per-entry key gradient
+          else atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k0 + kk, v);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- rows above FSW_LDS_MAX_DEG ------------------------------------------------------------------------------------------
+constexpr int kSweepDepthB = 4;
+
+__device__ __forceinline__ void sweep_pairs_b(float* __restrict__ sk, float* __restrict__ si, int Dp, int size, int st, bool flip) {
+  const int npairs = Dp >> 1;
+  const int half = size >> 1;
+  for (int i0 = lane_id(); i0 < npairs; i0 += kWave * kSweepDepthB) {
+    int ia[kSweepDepthB], ib[kSweepDepthB];
+    float ka[kSweepDepthB], kb[kSweepDepthB], pa[kSweepDepthB], pb[kSweepDepthB];
+#pragma unroll
+    for (int u = 0; u < kSweepDepthB; ++u) {
+      const int idx = i0 + u * kWave;
+      if (flip) {
+        const int blk = idx / half, off = idx - blk * half;
+        ia[u] = blk * size + off;
+        ib[u] = blk * size + size - 1 - off;
+      } else {
+        const int blk = idx / st, off = idx - blk * st;
+        ia[u] = blk * 2 * st + off;
+        ib[u] = ia[u] + st;
+      }
+      ka[u] = sk[ia[u]];
+      kb[u] = sk[ib[u]];
+      pa[u] = si[ia[u]];
+      pb[u] = si[ib[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kSweepDepthB; ++u) {
+      if (kb[u] < ka[u] || (kb[u] == ka[u] && __float_as_int(pb[u]) < __float_as_int(pa[u]))) {   // equal keys: by element index
+        sk[ia[u]] = kb[u];
+        sk[ib[u]] = ka[u];
+        si[ia[u]] = pb[u];
+        si[ib[u]] = pa[u];
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+}
+
+template <int M, bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ w, const int32_t* __restrict__ perm,
+                                                                const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
+                                                                int64_t ldp, int S, const float* __restrict__ freqs, float tau,
+                                                                const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
+                                                                float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
+                                                                const float* __restrict__ efeat, const float* __restrict__ Ve,
+                                                                int64_t ldve, int d_edge, float* __restrict__ gkey, int64_t ldk,
+                                                                char* __restrict__ scratch, int64_t wave_bytes) {
+  constexpr int CAP = M * kWave;
+  const int lane = lane_id();
+  const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
+  float* sk = reinterpret_cast<float*>(scratch + (int64_t)gw * wave_bytes);   // keys | element indices | contributions
+  float* si = sk + wave_bytes / 12;
+  float* sc = si + wave_bytes / 12;
+  const int pbeg = bin_start[FSW_BIN_GLOBAL], pend = bin_start[FSW_BIN_GLOBAL + 1];
+  const int64_t nlines = (int64_t)(pend - pbeg) * S;
+  for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
+    const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int Dtot = WEIGHTED ? D + 1 : D;
+    const int Dp = (int)pow2ceil((uint32_t)Dtot);
+    double m = (double)D;
+    float padw = 0.f;
+    if constexpr (WEIGHTED) {
+      double part = 0.0;
+      for (int t = lane; t < D; t += kWave) part += (double)(w ? w[start + t] : 1.f);
+      m = wave_sum_b64(part);
+      padw = (float)fmax((double)tau - m, 0.0);
+    }
+    const double inv = 1.0 / (WEIGHTED ? fmax(m, (double)tau) : m);
+    const double xi = (double)freqs[k];
+    const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
+    for (int c0 = 0; c0 < Dp; c0 += CAP) {
+      WaveLine<M, true, true> ln;
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int t = c0 + lane * M + j;
+        float key = __builtin_inff();
+        if (t < D) {
+          key = Xp[(int64_t)col[start + t] * ldp + k];
+          if (efeat) {
+            const float* er = efeat + (int64_t)(start + t) * d_edge;
+            const float* vr = Ve + (int64_t)k * ldve;
+            for (int q = 0; q < d_edge; ++q) key = fmaf(er[q], vr[q], key);
+          }
+        } else if (WEIGHTED && t == D) {
+          key = 0.f;
+        }
+        ln.k[j] = key;
+        ln.w[j] = __int_as_float(t);
+      }
+      ln.sort();
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        sk[c0 + lane * M + j] = ln.k[j];
+        si[c0 + lane * M + j] = ln.w[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    float gf = 0.f;
+    double carry = 0.0;
+    auto weight_of = [&](int id) { return id == D ? padw : (w ? w[start + id] : 1.f); };
+    for (int size = 2 * CAP; size <= Dp; size <<= 1) {
+      sweep_pairs_b(sk, si, Dp, size, 0, true);
+      for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs_b(sk, si, Dp, size, st, false);
+      const bool last = size == Dp;
+      for (int c0 = 0; c0 < Dp; c0 += CAP) {
+        if (last && c0 >= Dtot) break;
+        WaveLine<M, true, true> ln;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          ln.k[j] = sk[c0 + lane * M + j];
+          ln.w[j] = si[c0 + lane * M + j];
+        }
+        ln.merge_chunk();
+        if (!last) {
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            sk[c0 + lane * M + j] = ln.k[j];
+            si[c0 + lane * M + j] = ln.w[j];
+          }
+          continue;
+        }
+        double cbase = 0.0;
+        if constexpr (WEIGHTED) {
+          double part = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) part += (c0 + lane * M + j < Dtot) ? (double)weight_of(__float_as_int(ln.w[j])) : 0.0;
+          cbase = carry + wave_exclusive_scan_b64(part);
+          carry += wave_sum_b64(part);
+        }
+        gf += walk_line<M, WEIGHTED>(ln, c0 + lane * M, D, Dtot, xi, inv, gi, cbase, weight_of, [&](int id, float v) { sc[id] = v; });
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+    gf = wave_sum_b(gf);
+    if (lane == 0 && gfreq) atomicAdd(gfreq + k, gf);
+    for (int t = lane; t < D; t += kWave) {
+      const float v = sc[t];
+      if (gkey) gkey[(int64_t)(start + t) * ldk + k] = v;
+      else atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the next line reuses the scratch
+  }
+}
+
+// Scratch of the rows above FSW_LDS_MAX_DEG (forward: 4 or 8 bytes per element of the padded line and wave, backward 12):
+// room for up to 2048 resident waves, capped at 2 GiB -- fewer waves then share the lines of a very long row.
+size_t embed_global_scratch_bytes(int64_t max_degree) {
+  const size_t wave_bytes = (size_t)pow2ceil((uint32_t)(max_degree + 1)) * 12;
+  const size_t cap = (size_t)2 << 30;
+  size_t waves = std::min<size_t>(2048, cap / wave_bytes);
+  waves = std::max<size_t>(waves & ~(size_t)3, 4);
+  return waves * wave_bytes;
+}
+
+template <int M, bool WEIGHTED>
+static int launch_wsort_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, const float* g, int64_t ldg,
+                            float* gXp, int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_wsort_bwd<M, WEIGHTED>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWbLdsBytes));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)std::min<int64_t>(rows_upper, 1 << 14), kWbSplitY);
+  k_embed_wsort_bwd<M, WEIGHTED><<<grid, 256, kWbLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp,
+                                                                   a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq,
+                                                                   a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+// rows of FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (rows_upper bounds their number) or, global == true, above
+int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upper, const float* g, int64_t ldg, float* gXp,
+                          int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
+  if (rows_upper <= 0) return 0;
+  const bool unit = (a.w == nullptr) && (a.tau <= 1.f);
+  int rc;
+  if (global) {
+    FSW_REQUIRE(a.scratch && a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_backward: rows above FSW_LDS_MAX_DEG need the scratch buffer and max_degree");
+    const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
+    const int64_t wave_bytes = Dp * 12;
+    int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
+    nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 4) * 4) & ~(int64_t)3;
+    FSW_REQUIRE(nwaves >= 4, "fsw_embed_backward: scratch buffer too small (need fsw_embed_scratch_bytes(max_degree))");
+    char* scratch = reinterpret_cast<char*>(a.scratch);
+    if (unit)
+      k_embed_wsort_global_bwd<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
+          a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
+          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
+    else
+      k_embed_wsort_global_bwd<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
+          a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
+          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
+    FSW_LAUNCH_CHECK();
+    return 0;
+  }
+#define FSW_WB(M, WGT, LO, HI) \
+  if ((rc = launch_wsort_bwd<M, WGT>(a, LO, HI, rows_upper, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc
+  if (unit) {   // a wave holds 64 M elements
+    FSW_WB(4, false, FSW_BIN_MID0, FSW_BIN_LDS0 - 1);          // 33 .. 256
+    FSW_WB(8, false, FSW_BIN_LDS0, FSW_BIN_LDS0);
+    FSW_WB(16, false, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1);
+    FSW_WB(32, false, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2);
+  } else {      // D + 1 elements with the pad element: the bin of 256 and the LDS bins go one size up
+    FSW_WB(4, true, FSW_BIN_MID0, FSW_BIN_LDS0 - 2);           // 33 .. 192
+    FSW_WB(8, true, FSW_BIN_LDS0 - 1, FSW_BIN_LDS0 - 1);       // 193 .. 256
+    FSW_WB(16, true, FSW_BIN_LDS0, FSW_BIN_LDS0);
+    FSW_WB(32, true, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1);
+    FSW_WB(64, true, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2);
+  }
+#undef FSW_WB
+  return 0;
+}
+
+}  // namespace fsw

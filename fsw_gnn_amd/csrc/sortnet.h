@@ -48,6 +48,27 @@ struct PairNet {
   }
 };
 
+// (key, element index) pairs ordered by key, then index: a stable sort by key.  The index travels as float bits in w[].
+template <int D>
+struct IndexedNet {
+  float k[D];
+  float w[D];
+  template <int I, int J>
+  FSW_HD void cx() {
+    if constexpr (J < D) {
+      int ii, ij;
+      __builtin_memcpy(&ii, &w[I], 4);
+      __builtin_memcpy(&ij, &w[J], 4);
+      const bool sw = k[J] < k[I] || (k[J] == k[I] && ij < ii);
+      const float ki = k[I], kj = k[J], wi = w[I], wj = w[J];
+      k[I] = sw ? kj : ki;
+      k[J] = sw ? ki : kj;
+      w[I] = sw ? wj : wi;
+      w[J] = sw ? wi : wj;
+    }
+  }
+};
+
 template <class Net, int LO, int N, int R>
 struct OddEvenMerge {
   template <int I, int END, int STEP>

@@ -1,0 +1,144 @@
+// One slice's line of a long neighbourhood held across the registers of a wavefront, and its sort.  gfx950.
+//
+// Blocked layout: lane l holds elements l*M .. l*M+M-1 (keys, and one 32-bit payload per key when PAYLOAD: the weight
+// in the forward kernels, the element index in the backward kernels -- payloads only ever move, bit-exactly).  sort():
+// every lane sorts its M keys with the register network of sortnet.h, then six merge levels double the sorted run
+// (2, 4, .. 64 lanes): one "flip" exchange with lane ^ (lanes-1) and mirrored registers, log2(lanes)-1 exchanges
+// with lane ^ stride, log2(M) in-register half-cleaners.  merge_chunk(): the tail of a merge level for a chunk whose
+// halves were separated elsewhere (embed_wsort.hip, rows longer than one chunk).
+#pragma once
+#include <type_traits>
+#include "fsw_common.h"
+#include "sortnet.h"
+
+namespace fsw {
+
+// value of lane ^ MASK.  Distances inside a row of 16 lanes go through DPP (VALU rate, no LDS crossbar): xor 1, 2, 3 are
+// quad permutes, xor 7 / 15 the half-row / row mirrors, xor 4 = mirror7 o quad3, xor 8 = mirror15 o mirror7; xor 16 and 31
+// are ds_swizzle bit-mode patterns (inside 32 lanes); only 32 and 63 need ds_bpermute.
+template <int MASK>
+__device__ __forceinline__ float xor_lane(float v) {
+  const int x = __float_as_int(v);
+  auto dpp = [](int y, auto ctrl) { return __builtin_amdgcn_update_dpp(0, y, decltype(ctrl)::value, 0xF, 0xF, true); };
+  using std::integral_constant;
+  if constexpr (MASK == 1) return __int_as_float(dpp(x, integral_constant<int, 0xB1>{}));
+  else if constexpr (MASK == 2) return __int_as_float(dpp(x, integral_constant<int, 0x4E>{}));
+  else if constexpr (MASK == 3) return __int_as_float(dpp(x, integral_constant<int, 0x1B>{}));
+  else if constexpr (MASK == 7) return __int_as_float(dpp(x, integral_constant<int, 0x141>{}));
+  else if constexpr (MASK == 15) return __int_as_float(dpp(x, integral_constant<int, 0x140>{}));
+  else if constexpr (MASK == 4) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x141>{}), integral_constant<int, 0x1B>{}));
+  else if constexpr (MASK == 8) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x140>{}), integral_constant<int, 0x141>{}));
+  else if constexpr (MASK == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401F));
+  else if constexpr (MASK == 31) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x7C1F));
+  else return __shfl_xor(v, MASK);
+}
+
+// keys (and weights) of one line across the wave, blocked layout; ascending over element index l*M + j afterwards
+// TIEBREAK: the payload is the element index and equal keys are ordered by it (= a stable sort by key, the order the
+// reference's sort and the oracle produce; the backward kernels need it to hand tied neighbours the same coefficients)
+template <int M, bool WEIGHTED, bool TIEBREAK = false>
+struct WaveLine {
+  float k[M];
+  float w[WEIGHTED ? M : 1];
+
+  // exchange with another lane: this lane keeps the smaller (lower == true) or the larger key of each pair
+  template <int JREV, int MASK>
+  __device__ __forceinline__ void exchange(bool lower) {
+    float ok[M], ow[WEIGHTED ? M : 1];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      ok[j] = xor_lane<MASK>(k[JREV ? M - 1 - j : j]);
+      if constexpr (WEIGHTED) ow[j] = xor_lane<MASK>(w[JREV ? M - 1 - j : j]);
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      if constexpr (WEIGHTED) {
+        bool take = lower ? (ok[j] < k[j]) : (ok[j] > k[j]);   // ties: both lanes keep their own element
+        if constexpr (TIEBREAK) {
+          const int oi = __float_as_int(ow[j]), mi = __float_as_int(w[j]);
+          take = take || (ok[j] == k[j] && (lower ? oi < mi : oi > mi));
+        }
+        k[j] = take ? ok[j] : k[j];
+        w[j] = take ? ow[j] : w[j];
+      } else {
+        k[j] = lower ? fminf(k[j], ok[j]) : fmaxf(k[j], ok[j]);
+      }
+    }
+  }
+  __device__ __forceinline__ void cx(int i, int j) {
+    if constexpr (WEIGHTED) {
+      bool sw = k[j] < k[i];
+      if constexpr (TIEBREAK) sw = sw || (k[j] == k[i] && __float_as_int(w[j]) < __float_as_int(w[i]));
+      const float ki = k[i], kj = k[j], wi = w[i], wj = w[j];
+      k[i] = sw ? kj : ki;
+      k[j] = sw ? ki : kj;
+      w[i] = sw ? wj : wi;
+      w[j] = sw ? wi : wj;
+    } else {
+      const float lo = fminf(k[i], k[j]), hi = fmaxf(k[i], k[j]);
+      k[i] = lo;
+      k[j] = hi;
+    }
+  }
+  __device__ __forceinline__ void sort() {
+    const int lane = lane_id();
+    // every lane: its own M elements
+    if constexpr (WEIGHTED && TIEBREAK) {
+      IndexedNet<M> net;
+#pragma unroll
+      for (int j = 0; j < M; ++j) { net.k[j] = k[j]; net.w[j] = w[j]; }
+      sort_network<M>(net);
+#pragma unroll
+      for (int j = 0; j < M; ++j) { k[j] = net.k[j]; w[j] = net.w[j]; }
+    } else if constexpr (WEIGHTED) {
+      PairNet<M> net;
+#pragma unroll
+      for (int j = 0; j < M; ++j) { net.k[j] = k[j]; net.w[j] = w[j]; }
+      sort_network<M>(net);
+#pragma unroll
+      for (int j = 0; j < M; ++j) { k[j] = net.k[j]; w[j] = net.w[j]; }
+    } else {
+      KeyNet<M> net;
+#pragma unroll
+      for (int j = 0; j < M; ++j) net.k[j] = k[j];
+      sort_network<M>(net);
+#pragma unroll
+      for (int j = 0; j < M; ++j) k[j] = net.k[j];
+    }
+    merge_levels<2>(lane);
+  }
+  // merge levels: sorted runs of LANES/2 lanes -> runs of LANES lanes (template recursion: every exchange mask is a
+  // compile-time constant, so the compiler can use DPP / swizzles for the short ones)
+  template <int LANES>
+  __device__ __forceinline__ void merge_levels(int lane) {
+    if constexpr (LANES <= kWave) {
+      exchange<1, LANES - 1>((lane & (LANES >> 1)) == 0);          // element i against i ^ (LANES*M - 1)
+      half_cleaners<(LANES >> 2)>(lane);
+#pragma unroll
+      for (int st = M >> 1; st >= 1; st >>= 1)
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+          if ((j & st) == 0) cx(j, j + st);
+      merge_levels<LANES * 2>(lane);
+    }
+  }
+  // the 64 M elements form a bitonic sequence whose halves were already separated: finish the merge
+  __device__ __forceinline__ void merge_chunk() {
+    const int lane = lane_id();
+    half_cleaners<(kWave >> 1)>(lane);
+#pragma unroll
+    for (int st = M >> 1; st >= 1; st >>= 1)
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if ((j & st) == 0) cx(j, j + st);
+  }
+  template <int ST>
+  __device__ __forceinline__ void half_cleaners(int lane) {
+    if constexpr (ST >= 1) {
+      exchange<0, ST>((lane & ST) == 0);
+      half_cleaners<(ST >> 1)>(lane);
+    }
+  }
+};
+
+}  // namespace fsw

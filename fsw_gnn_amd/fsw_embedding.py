@@ -9,7 +9,7 @@ sort + cumulative-sum + Fourier readout kernels (fsw_embed_f32).  There is no CP
 tensors must live on a HIP device and the native library must be present.
 
 Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kernels, csrc/embed_bwd.hip and
-csrc/embed_lds.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
+csrc/embed_wsort_bwd.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
 total-mass scale (the weights W are constants).
 Edge features (d_edge > 0) go through the coalescing CSR build and the general-weight kernels.
 Not implemented (raise NotImplementedError): Cartesian mode (nSlices x nFreqs), gradients w.r.t. W.

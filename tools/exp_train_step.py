@@ -1,21 +1,35 @@
-"""Timing of one FSW_conv training step (forward + backward) at BASELINE config 3 -- not the headline metric."""
-import os, sys, time, torch
+"""Timing of one FSW_conv training step (forward + backward) -- not the headline metric.
+
+    python tools/exp_train_step.py            BASELINE config 3 (ER multigraph, every row on the <= 32 register path)
+    python tools/exp_train_step.py --rmat 20  RMAT graph with 2^20 vertices and 10M edges (hubs up to 41 300 neighbours)
+"""
+import argparse, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from fsw_gnn_amd import FSW_conv
+from fsw_gnn_amd import FSW_conv, synth
+ap = argparse.ArgumentParser()
+ap.add_argument("--rmat", type=int, default=0)
+ap.add_argument("--forward-only", action="store_true")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
 n, E = bench.N_NODES, bench.N_EDGES
-x, ei = bench.make_inputs(n, E, dev)
+if args.rmat:
+    n = 1 << args.rmat
+    ei = torch.from_numpy(synth.rmat_graph(args.rmat, E, 7)).to(dev)
+    x = torch.from_numpy(synth.features(n, 128, 3)).to(dev)
+else:
+    x, ei = bench.make_inputs(n, E, dev)
 conv = FSW_conv(128, 128, embed_dim=257, device=dev)
-x.requires_grad_(True)
-def step():
-    conv.zero_grad(set_to_none=True); x.grad = None
-    y = conv(x, ei)
-    y.square().mean().backward()
-for _ in range(2): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5): step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-print("training step (fwd + bwd), 1M nodes / 10M edges / 256 slices: %.2f ms" % (dt * 1e3))
 with torch.no_grad():
-    print("inference forward: %.2f ms" % bench.timed_ms(lambda: conv(x.detach(), ei), 5, dev))
+    print("inference forward, %d nodes / %d edges / 256 slices: %.2f ms" % (n, E, bench.timed_ms(lambda: conv(x, ei), 5, dev)), flush=True)
+if not args.forward_only:
+    x.requires_grad_(True)
+    def step():
+        conv.zero_grad(set_to_none=True); x.grad = None
+        y = conv(x, ei)
+        y.square().mean().backward()
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print("training step (fwd + bwd): %.2f ms" % (dt * 1e3))

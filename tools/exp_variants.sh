@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     objs=""
-    for f in api graph_build project embed_reg embed_mid_0 embed_mid_1 embed_mid_2 embed_wsort embed_lds embed_api conv_fused embed_bwd segcumsum; do
+    for f in api graph_build project embed_reg embed_mid_0 embed_mid_1 embed_mid_2 embed_wsort embed_wsort_bwd embed_api conv_fused embed_bwd segcumsum; do
       case "$f" in
         embed_reg|conv_fused|project|graph_build) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $src/$f.hip -o $o ;;
         *) o=$src/_build/$f.o ;;
