@@ -408,6 +408,9 @@ static int launch_wsort_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int
   return 0;
 }
 
+int launch_embed_mid_bwd(const fsw_embed_args& a, int64_t rows_upper, const float* g, int64_t ldg, float* gXp, int64_t ldgp,
+                         float* gfreq, float* gkey, int64_t ldk, hipStream_t stream);
+
 // rows of FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (rows_upper bounds their number) or, global == true, above
 int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upper, const float* g, int64_t ldg, float* gXp,
                           int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
@@ -435,13 +438,16 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
   }
 #define FSW_WB(M, WGT, LO, HI) \
   if ((rc = launch_wsort_bwd<M, WGT>(a, LO, HI, rows_upper, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc
+  // 33 .. 128: one lane per slice (embed_mid_bwd.hip)
+  if ((rc = launch_embed_mid_bwd(a, rows_upper, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc;
+  constexpr int kFirst = FSW_BIN_MID0 + 6;                     // first bin above FSW_MID_MAX_DEG_WEIGHTED = 128
   if (unit) {   // a wave holds 64 M elements
-    FSW_WB(4, false, FSW_BIN_MID0, FSW_BIN_LDS0 - 1);          // 33 .. 256
+    FSW_WB(4, false, kFirst, FSW_BIN_LDS0 - 1);                // 129 .. 256
     FSW_WB(8, false, FSW_BIN_LDS0, FSW_BIN_LDS0);
     FSW_WB(16, false, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1);
     FSW_WB(32, false, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2);
   } else {      // D + 1 elements with the pad element: the bin of 256 and the LDS bins go one size up
-    FSW_WB(4, true, FSW_BIN_MID0, FSW_BIN_LDS0 - 2);           // 33 .. 192
+    FSW_WB(4, true, kFirst, FSW_BIN_LDS0 - 2);                 // 129 .. 192
     FSW_WB(8, true, FSW_BIN_LDS0 - 1, FSW_BIN_LDS0 - 1);       // 193 .. 256
     FSW_WB(16, true, FSW_BIN_LDS0, FSW_BIN_LDS0);
     FSW_WB(32, true, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1);
