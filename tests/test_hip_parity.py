@@ -744,3 +744,37 @@ def test_slice_parallel_conv_matches_single_gpu(dev, world, tmp_path):
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     assert "DIST_OK" in outs[0][0]
+
+
+_RCCL_WORKER = """
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # "nccl" is RCCL on ROCm
+from fsw_gnn_amd.dist import all_gather_slice_blocks, slice_partition
+n, S = 1000, 37
+local = torch.randn((n, 1 + S), device=dev)
+out = torch.empty((n, 1 + S + 5), device=dev)
+all_gather_slice_blocks(local, slice_partition(S, 1), 1, out)
+torch.cuda.synchronize()
+assert torch.equal(out[:, :1 + S], local)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_backend_runs_the_gather_collective(dev, tmp_path):
+    """The collective of the slice-parallel path on the real backend (RCCL; one rank is all a one-GPU box allows --
+    the multi-rank logic is covered by the gloo tests above and in tests/test_host_cpu.py)."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-2000:]
