@@ -655,11 +655,13 @@ def test_edge_features_conv_forward_and_backward(dev, tag, slw):
 
 
 def test_edge_features_embedding_sparse_inputs_and_long_rows(dev):
-    """FSW_embedding(d_edge > 0).forward(X, W sparse, X_edge sparse) incl. one row of 300 neighbours (LDS path)."""
+    """FSW_embedding(d_edge > 0).forward(X, W sparse, X_edge sparse) incl. rows of 60 / 150 / 300 / 2500 neighbours
+    (padded register path, wave-sort path with 8 and 16 keys per lane, chunked scratch path; all with general weights)."""
     rng = np.random.default_rng(5)
-    n, d, de, S = 400, 6, 2, 12
-    src = np.concatenate([rng.integers(0, n, 1500), np.arange(300)])
-    dst = np.concatenate([rng.integers(1, n, 1500), np.zeros(300, dtype=np.int64)])
+    n, d, de, S = 2600, 6, 2, 12
+    long_rows = {0: 300, 1: 60, 2: 150, 3: 2500}
+    src = np.concatenate([rng.integers(0, n, 1500)] + [rng.choice(n, size=k, replace=False) for k in long_rows.values()])
+    dst = np.concatenate([rng.integers(4, n, 1500)] + [np.full(k, r, dtype=np.int64) for r, k in long_rows.items()])
     key = np.unique(dst * n + src)
     dst, src = key // n, key % n
     wv = (rng.random(key.shape[0]) + 0.2).astype(np.float32)
@@ -674,11 +676,19 @@ def test_edge_features_embedding_sparse_inputs_and_long_rows(dev):
         W = torch.sparse_coo_tensor(idx, t(wv, dev), (n, n)).coalesce()
         Xe = torch.sparse_coo_tensor(idx, t(ef, dev), (n, n, de)).coalesce()
         out = E(t(X, dev), W, Xe, graph_mode=True).cpu().numpy()
-        out_d = E(t(X, dev), W.to_dense(), Xe.to_dense(), graph_mode=True).cpu().numpy()      # dense W / X_edge
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))])
     ref = O.fsw_embedding_forward(X, rowptr, src, wv, V, fr, edge_feat=ef)
-    assert np.diff(rowptr).max() >= 300
-    assert relerr(out, ref) < TOL and relerr(out_d, ref) < TOL
+    assert np.diff(rowptr)[:4].tolist() == [300, 60, 150, 2500]
+    assert relerr(out, ref) < TOL and relerr(out[:4], ref[:4]) < TOL
+    m = 400                                                  # dense W / X_edge on a sub-block (dense n x n x de would be 54 MB)
+    keep = (dst < m) & (src < m)
+    with torch.no_grad():
+        idx2 = torch.from_numpy(np.stack([dst[keep], src[keep]])).to(dev)
+        Wd = torch.sparse_coo_tensor(idx2, t(wv[keep], dev), (m, m)).to_dense()
+        Xed = torch.sparse_coo_tensor(idx2, t(ef[keep], dev), (m, m, de)).to_dense()
+        out_d = E(t(X[:m], dev), Wd, Xed, graph_mode=True).cpu().numpy()
+    rp2 = np.concatenate([[0], np.cumsum(np.bincount(dst[keep], minlength=m))])
+    assert relerr(out_d, O.fsw_embedding_forward(X[:m], rp2, src[keep], wv[keep], V, fr, edge_feat=ef[keep])) < TOL
 
 
 @pytest.mark.parametrize("n,E,d,S", [(3000, 25000, 128, 1000), (2000, 15000, 256, 96), (1500, 12000, 100, 300)])
