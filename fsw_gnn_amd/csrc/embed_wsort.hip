@@ -205,7 +205,17 @@ __global__ void __launch_bounds__(256) k_embed_wsort(const int32_t* __restrict__
 // readout instead of going back to memory.  Any in-degree works; the scratch holds 4 (unit) or 8 bytes per element of the
 // padded line and wave.  The gather is one 4-byte read per neighbour and slice here (the four waves of a workgroup take
 // adjacent slices, so they share sectors): these rows are few.
-constexpr int kSweepDepth = 4;
+#ifndef FSW_SWEEP_DEPTH
+#define FSW_SWEEP_DEPTH 4
+#endif
+constexpr int kSweepDepth = FSW_SWEEP_DEPTH;
+#ifndef FSW_WSG_ABL
+#define FSW_WSG_ABL 0   // timing experiments on k_embed_wsort_global: 1 no gather, 2 no register sorts, 4 no sweeps, 8 agent-scope fences
+#endif
+// Orders a wave's scratch-line stores before the loads of its next pass (other lanes of the SAME wave read them).
+// Workgroup scope is enough: the wave's loads and stores go through the one L1 of its CU, which stays coherent for the
+// CU's own stores; an agent-scope fence also invalidates that L1 for every resident wave and made this kernel 2.6x slower.
+#define FSW_WSG_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, (FSW_WSG_ABL & 8) ? "agent" : "workgroup")
 
 template <bool WEIGHTED>
 __device__ __forceinline__ void sweep_pairs(float* __restrict__ sk, float* __restrict__ sw, int Dp, int size, int st, bool flip) {
@@ -250,7 +260,7 @@ __device__ __forceinline__ void sweep_pairs(float* __restrict__ sk, float* __res
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the next sweep reads what other lanes of this wave wrote
+  FSW_WSG_FENCE();   // the next sweep reads what other lanes of this wave wrote
 }
 
 template <int M, bool WEIGHTED>
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
         const int t = c0 + lane * M + j;
         float key = __builtin_inff(), wt = 0.f;
         if (t < D) {
-          key = Xp[(int64_t)col[start + t] * ldp + k];
+          key = (FSW_WSG_ABL & 1) ? (float)((t * 2654435761u) >> 8) : Xp[(int64_t)col[start + t] * ldp + k];
           if (efeat) {   // edge features: + <e_ij, v_k[d_in:]> (reference fsw_embedding.py:934-968)
             const float* er = efeat + (int64_t)(start + t) * d_edge;
             const float* vr = Ve + (int64_t)k * ldve;
@@ -312,14 +322,14 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
         ln.k[j] = key;
         if constexpr (WEIGHTED) ln.w[j] = wt;
       }
-      ln.sort();
+      if (!(FSW_WSG_ABL & 2)) ln.sort();
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         sk[c0 + lane * M + j] = ln.k[j];
         if constexpr (WEIGHTED) sw[c0 + lane * M + j] = ln.w[j];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    FSW_WSG_FENCE();
     // B. merge levels
     float acc = 0.f;
     double carry = 0.0;                                 // cumulative weight before the current chunk (weighted readout)
@@ -327,8 +337,10 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
     const double step = xi * inv;                       // revolutions per rank (unit weights)
     if (!WEIGHTED && !lin) sincospi(2.0 * (step - rint(step)), &sd, &cd);
     for (int size = 2 * CAP; size <= Dp; size <<= 1) {
-      sweep_pairs<WEIGHTED>(sk, sw, Dp, size, 0, true);
-      for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs<WEIGHTED>(sk, sw, Dp, size, st, false);
+      if (!(FSW_WSG_ABL & 4)) {
+        sweep_pairs<WEIGHTED>(sk, sw, Dp, size, 0, true);
+        for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs<WEIGHTED>(sk, sw, Dp, size, st, false);
+      }
       const bool last = size == Dp;
       for (int c0 = 0; c0 < Dp; c0 += CAP) {
         if (last && c0 >= Dtot) break;                  // only +inf padding from here on
@@ -338,7 +350,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
           ln.k[j] = sk[c0 + lane * M + j];
           if constexpr (WEIGHTED) ln.w[j] = sw[c0 + lane * M + j];
         }
-        ln.merge_chunk();
+        if (!(FSW_WSG_ABL & 2)) ln.merge_chunk();
         if (!last) {
 #pragma unroll
           for (int j = 0; j < M; ++j) {
@@ -389,7 +401,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      FSW_WSG_FENCE();
     }
     acc = wave_sum_w(acc) * (lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiW * xi)));
     if (lane == 0) {

@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
 }
 
 // ---- rows above FSW_LDS_MAX_DEG ------------------------------------------------------------------------------------------
+// fences below: workgroup scope orders a wave's scratch stores before its own later loads (same CU, same L1; see embed_wsort.hip)
 constexpr int kSweepDepthB = 4;
 
 __device__ __forceinline__ void sweep_pairs_b(float* __restrict__ sk, float* __restrict__ si, int Dp, int size, int st, bool flip) {
@@ -268,7 +269,7 @@ __device__ __forceinline__ void sweep_pairs_b(float* __restrict__ sk, float* __r
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
 template <int M, bool WEIGHTED>
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
         si[c0 + lane * M + j] = ln.w[j];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     float gf = 0.f;
     double carry = 0.0;
     auto weight_of = [&](int id) { return id == D ? padw : (w ? w[start + id] : 1.f); };
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
         }
         gf += walk_line<M, WEIGHTED>(ln, c0 + lane * M, D, Dtot, xi, inv, gi, cbase, weight_of, [&](int id, float v) { sc[id] = v; });
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     gf = wave_sum_b(gf);
     if (lane == 0 && gfreq) atomicAdd(gfreq + k, gf);
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
       if (gkey) gkey[(int64_t)(start + t) * ldk + k] = v;
       else atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k, v);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the next line reuses the scratch
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the next line reuses the scratch
   }
 }
 

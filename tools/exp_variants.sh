@@ -10,11 +10,13 @@ if [ "$1" = build ]; then
   mkdir -p "$out"
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
+    # the translation units that honour experiment flags are rebuilt, every other object comes from the regular build
     objs=""
-    for f in api graph_build project embed_reg embed_mid_0 embed_mid_1 embed_mid_2 embed_wsort embed_wsort_bwd embed_api conv_fused embed_bwd segcumsum; do
+    for o in $src/_build/*.o; do
+      f=$(basename $o .o)
       case "$f" in
-        embed_reg|conv_fused|project|graph_build) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $src/$f.hip -o $o ;;
-        *) o=$src/_build/$f.o ;;
+        embed_reg|conv_fused|project|graph_build|embed_wsort) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -c $src/$f.hip -o $o ;;
+        embed_mid|embed_lds) continue ;;   # stale objects of removed / split sources
       esac
       objs="$objs $o"
     done
