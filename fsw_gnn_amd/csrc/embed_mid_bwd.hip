@@ -16,15 +16,24 @@ namespace fsw {
 
 constexpr double kPiMB = 3.14159265358979323846;
 
-__device__ __forceinline__ void F_dF_sc_m(double xi, double c, double s, double co, double& F, double& dF) {
-  const double x = 2.0 * kPiMB * xi * c;
+struct FCoefM {
+  double xi, a1, a2, a3;   // a1 = (1 + xi)/(pi xi), a2 = 1/(pi xi^2), a3 = 2 (1 + xi)/xi: no division left per element
+  __device__ __forceinline__ explicit FCoefM(double x) : xi(x) {
+    const double r = x > 0.0 ? 1.0 / x : 0.0;
+    a1 = (1.0 + x) * r * (1.0 / kPiMB);
+    a2 = r * r * (1.0 / kPiMB);
+    a3 = 2.0 * (1.0 + x) * r;
+  }
+};
+__device__ __forceinline__ void F_dF_sc_m(const FCoefM& f, double c, double s, double co, double& F, double& dF) {
+  const double x = 2.0 * kPiMB * f.xi * c;
   if (x < 1e-4) {   // series: the two terms of dF cancel for tiny phases; xi == 0 gives F = dF = 2 c
     const double q = 1.0 - x * x * (1.0 / 6.0);
-    F = (1.0 + xi) * 2.0 * c * q;
-    dF = 2.0 * c * q - (1.0 + xi) * 2.0 * c * (2.0 * kPiMB * c) * (2.0 * kPiMB * c) * xi * (1.0 / 3.0);
+    F = (1.0 + f.xi) * 2.0 * c * q;
+    dF = 2.0 * c * q - (1.0 + f.xi) * 2.0 * c * (2.0 * kPiMB * c) * (2.0 * kPiMB * c) * f.xi * (1.0 / 3.0);
   } else {
-    F = (1.0 + xi) * s / (kPiMB * xi);
-    dF = -s / (kPiMB * xi * xi) + (1.0 + xi) * 2.0 * c * co / xi;
+    F = f.a1 * s;
+    dF = fma(f.a3 * c, co, -(f.a2 * s));
   }
 }
 
@@ -49,6 +58,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
   float* tile = smem + wave_id() * (DP * kWave) + lane;   // [element][lane] of this wave
   const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
   const double xi = (double)freqs[kc];
+  const FCoefM fc(xi);
   const double taud = (double)tau;
   float gf = 0.f;
   for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
@@ -92,7 +102,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
           s = sn;
           c = cn;
           double F, dF;
-          F_dF_sc_m(xi, (double)(r + 1) * inv, s, c, F, dF);
+          F_dF_sc_m(fc, (double)(r + 1) * inv, s, c, F, dF);
           tile[__float_as_int(net.w[r]) * kWave] = gi * (float)(F - Fp);
           gf = fmaf(gi * (float)(dF - dFp), net.k[r], gf);
           Fp = F;
@@ -109,7 +119,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
           const double ph = xi * (c * inv);
           double s, co, F, dF;
           sincospi(2.0 * (ph - rint(ph)), &s, &co);
-          F_dF_sc_m(xi, c * inv, s, co, F, dF);
+          F_dF_sc_m(fc, c * inv, s, co, F, dF);
           if (id < D) tile[id * kWave] = gi * (float)(F - Fp);   // the pad element has no source row
           gf = fmaf(gi * (float)(dF - dFp), net.k[r], gf);
           Fp = F;

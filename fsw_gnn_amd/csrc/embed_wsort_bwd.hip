@@ -24,6 +24,9 @@ namespace fsw {
 constexpr double kPiB = 3.14159265358979323846;
 constexpr int kWbLdsBytes = 69 * 1024;
 constexpr int kWbSplitY = 4;
+#ifndef FSW_WSB_ABL
+#define FSW_WSB_ABL 0   // timing experiments on k_embed_wsort_bwd: 1 no atomics, 2 no sort, 4 no coefficient walk
+#endif
 
 __device__ __forceinline__ float wave_sum_b(float v) {
 #pragma unroll
@@ -46,23 +49,32 @@ __device__ __forceinline__ double wave_exclusive_scan_b64(double v) {
 }
 
 // F and dF/dxi at normalised cumulative weight c, given sin and cos of 2 pi xi c; series for tiny phases (the two terms
-// of dF cancel there); xi == 0: F = 2 c, dF = 2 c.
-__device__ __forceinline__ void F_dF_sc(double xi, double c, double s, double co, double& F, double& dF) {
-  const double x = 2.0 * kPiB * xi * c;
+// of dF cancel there); xi == 0: F = 2 c, dF = 2 c.  FCoef holds the per-slice factors so that no division is left per element.
+struct FCoef {
+  double xi, a1, a2, a3;   // a1 = (1 + xi)/(pi xi), a2 = 1/(pi xi^2), a3 = 2 (1 + xi)/xi
+  __device__ __forceinline__ explicit FCoef(double x) : xi(x) {
+    const double r = x > 0.0 ? 1.0 / x : 0.0;
+    a1 = (1.0 + x) * r * (1.0 / kPiB);
+    a2 = r * r * (1.0 / kPiB);
+    a3 = 2.0 * (1.0 + x) * r;
+  }
+};
+__device__ __forceinline__ void F_dF_sc(const FCoef& f, double c, double s, double co, double& F, double& dF) {
+  const double x = 2.0 * kPiB * f.xi * c;
   if (x < 1e-4) {
     const double q = 1.0 - x * x * (1.0 / 6.0);
-    F = (1.0 + xi) * 2.0 * c * q;
-    dF = 2.0 * c * q - (1.0 + xi) * 2.0 * c * (2.0 * kPiB * c) * (2.0 * kPiB * c) * xi * (1.0 / 3.0);
+    F = (1.0 + f.xi) * 2.0 * c * q;
+    dF = 2.0 * c * q - (1.0 + f.xi) * 2.0 * c * (2.0 * kPiB * c) * (2.0 * kPiB * c) * f.xi * (1.0 / 3.0);
   } else {
-    F = (1.0 + xi) * s / (kPiB * xi);
-    dF = -s / (kPiB * xi * xi) + (1.0 + xi) * 2.0 * c * co / xi;
+    F = f.a1 * s;
+    dF = fma(f.a3 * c, co, -(f.a2 * s));
   }
 }
-__device__ __forceinline__ void F_dF(double xi, double c, double& F, double& dF) {
-  const double ph = xi * c;
+__device__ __forceinline__ void F_dF(const FCoef& f, double c, double& F, double& dF) {
+  const double ph = f.xi * c;
   double s, co;
   sincospi(2.0 * (ph - rint(ph)), &s, &co);
-  F_dF_sc(xi, c, s, co, F, dF);
+  F_dF_sc(f, c, s, co, F, dF);
 }
 
 // Walks the sorted line held by `ln` (ranks r0 + j, j < M, of a line of Dtot elements of which the first D are
@@ -74,20 +86,21 @@ __device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, in
                                            double cbase, WeightFn weight_of, EmitFn emit) {
   float gf = 0.f;
   double Fp, dFp;
+  const FCoef fc(xi);
   if constexpr (!WEIGHTED) {
     const double step = xi * inv;   // revolutions per rank
     double sd, cd, s, c;
     sincospi(2.0 * (step - rint(step)), &sd, &cd);
     const double x0 = step * (double)r0;
     sincospi(2.0 * (x0 - rint(x0)), &s, &c);
-    F_dF_sc(xi, (double)r0 * inv, s, c, Fp, dFp);
+    F_dF_sc(fc, (double)r0 * inv, s, c, Fp, dFp);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
       s = sn;
       c = cn;
       double F, dF;
-      F_dF_sc(xi, (double)min(r0 + j + 1, D) * inv, s, c, F, dF);
+      F_dF_sc(fc, (double)min(r0 + j + 1, D) * inv, s, c, F, dF);
       if (r0 + j < D) {
         emit(__float_as_int(ln.w[j]), gi * (float)(F - Fp));
         gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
@@ -97,14 +110,14 @@ __device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, in
     }
   } else {
     double c = cbase;
-    F_dF(xi, c * inv, Fp, dFp);
+    F_dF(fc, c * inv, Fp, dFp);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       const int id = __float_as_int(ln.w[j]);
       const bool valid = r0 + j < Dtot;
       c += valid ? (double)weight_of(id) : 0.0;
       double F, dF;
-      F_dF(xi, c * inv, F, dF);
+      F_dF(fc, c * inv, F, dF);
       if (valid) {
         if (id < D) emit(id, gi * (float)(F - Fp));   // the pad element (id == D) has no source row
         gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
@@ -199,7 +212,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
           ln.k[j] = t < Dtot ? line[lane * (M + 1) + j] : __builtin_inff();
           ln.w[j] = __int_as_float(t);
         }
-        ln.sort();
+        if (!(FSW_WSB_ABL & 2)) ln.sort();
         const double xi = (double)freqs[k];
         const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
         double cbase = 0.0;
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
           }
           cbase = wave_exclusive_scan_b64(part);
         }
-        float gf = walk_line<M, WEIGHTED>(
+        float gf = (FSW_WSB_ABL & 4) ? 0.f : walk_line<M, WEIGHTED>(
             ln, lane * M, D, Dtot, xi, inv, gi, cbase, [&](int id) { return wrow[id + id / M]; },
             [&](int id, float v) { line[id + id / M] = v; });   // every lane has read its keys: the line is free
         gf = wave_sum_b(gf);
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
         if (k0 + kk < S) {
           const float v = tile[kk * LINE + t + t / M];
           if (gkey) gkey[(int64_t)(start + t) * ldk + k0 + kk] = v;   // edge features: per-entry key gradient
-          else atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k0 + kk, v);
+          else if (!(FSW_WSB_ABL & 1)) atomicAdd(gXp + (int64_t)col[start + t] * ldgp + k0 + kk, v);
         }
       }
       __syncthreads();
