@@ -256,7 +256,7 @@ def test_mid_degree_rows_every_padded_network_size(dev):
     rng = np.random.default_rng(21)
     sizes = [33, 40, 41, 48, 49, 64, 65, 80, 81, 96, 97, 128, 129, 160, 161, 192, 193, 255, 256, 257, 300, 35, 100]
     assert set(_lib.MID_SIZES) <= set(sizes)
-    nrows, n, d, S = len(sizes), 600, 12, 70
+    nrows, n, d, S = len(sizes), 600, 12, 270                     # > 256 slices: two chunk groups
     X = rng.standard_normal((n, d)).astype(np.float32)
     V = cases.synth.unit_slices(S, d, seed=85)
     fr = cases.random_freqs(S, seed=86)
@@ -293,7 +293,7 @@ def test_wave_sort_rows_every_size_class(dev):
     from fsw_gnn_amd import build_csr, _lib
     rng = np.random.default_rng(23)
     sizes = [257, 512, 513, 1024, 1025, 2048, 600]
-    nrows, n, d, S = len(sizes), 2300, 8, 21
+    nrows, n, d, S = len(sizes), 2300, 8, 277                    # > 256 slices: several chunk groups on every path
     X = rng.standard_normal((n, d)).astype(np.float32)
     V = cases.synth.unit_slices(S, d, seed=89)
     fr = cases.random_freqs(S, seed=90)
