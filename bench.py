@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
+    ap.add_argument("--shard", choices=("nodes", "slices"), default="nodes",
+                    help="N > 1: 'nodes' = every rank runs the fused layer on its block of recipient rows, all-gather of the "
+                         "128-wide output; 'slices' = BASELINE north_star's slice-axis shard, all-gather of the 257-wide embedding")
     return ap.parse_args()
 
 
@@ -171,6 +174,32 @@ def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
             "ms_per_launch": kms}
 
 
+def node_sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
+    """N > 1, recipient-row sharding: the dominant kernel of a rank is k_conv_fused_unit over its block of rows."""
+    from fsw_gnn_amd import _lib
+    from fsw_gnn_amd.graph import build_csr
+    emb = conv.fsw_embed
+    per = -(-n // world)
+    r0 = min(rank * per, n)
+    nl = min(r0 + per, n) - r0
+    mine = (ei[1] >= r0) & (ei[1] < r0 + nl)
+    graph = build_csr(ei[1][mine] - r0, ei[0][mine], None, nl, n, want_invperm=True)
+    wq, w2 = conv._fused_weight()
+    prepared = emb.prepare(x, graph)
+    st = prepared["stats"]
+    assert st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0
+    H = conv.mlp[0].out_features
+    yin = torch.empty((nl, H), dtype=torch.float32, device=dev)
+    y = torch.empty((nl, H), dtype=torch.float32, device=dev)
+    kms = timed_ms(lambda: conv._fused_linear(graph, prepared, 1.0, wq, yin, y), reps, dev)
+    edges = int(graph.rowptr[-1])
+    alg_bytes = 4.0 * edges * emb.nSlices + 4.0 * edges + 8.0 * nl + 8.0 * nl * H
+    return {"bound": "hbm", "kernel": "k_conv_fused_unit (rank 0: %d of %d rows)" % (nl, n),
+            "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "ms_per_launch": kms}
+
+
 def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     """C oracle (port of the reference algorithm) on the host cores: slices [0, nslices) of the same workload."""
     from oracle import c_oracle as C
@@ -219,7 +248,10 @@ def main():
     if args.no_fuse:
         conv.fuse_linear = False
     if world > 1:
-        conv.enable_slice_parallel(None)
+        if args.shard == "nodes" and not args.no_fuse:
+            conv.enable_node_parallel(None)
+        else:
+            conv.enable_slice_parallel(None)
     S = conv.fsw_embed.nSlices
     keys = ei[1] * n + ei[0]
     e_coalesced = int(torch.unique(keys).numel())          # E' of SURVEY 8(d): edges after the reference's coalesce()
@@ -259,7 +291,9 @@ def main():
                                "FSW_conv(%d->%d, embed_dim=%d), full forward incl. CSR build and Linear layer"
                                % (n, E, e_coalesced, D_FEAT, S, D_FEAT, OUT_CH, EMBED_DIM),
                    "nodes": n, "edges": E, "edges_coalesced": e_coalesced, "slices": S, "features": D_FEAT,
-                   "parallelism": "slice-shard x%d + all-gather" % world if world > 1 else "single GPU"},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "recipient-row shard x%d, all-gather of the output rows" % world if getattr(conv, "_node_parallel", False)
+                                   else "slice-shard x%d, all-gather of the embedding" % world)},
         # fraction of the 8 TB/s roofline for the WHOLE forward at SURVEY 8(d)'s 5.13 B per edge*slice (incl. CSR build)
         "path_roofline_frac": value * 5.13 / (HBM_PEAK_GBS * 1e9),
     }
@@ -270,7 +304,8 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
     if world > 1:
-        roof = sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)   # every rank runs it
+        fn = node_sharded_kernel_roofline if getattr(conv, "_node_parallel", False) else sharded_kernel_roofline
+        roof = fn(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)   # every rank runs it
         if rank == 0:
             result["roofline"] = roof
     if rank == 0:

@@ -231,6 +231,10 @@ class FSW_conv(_Base):
                                                   or (edge_features is not None and edge_features.requires_grad))
         n = vertex_features.size(0)
         x = vertex_features.contiguous()
+        if getattr(self, '_node_parallel', False):
+            if needs_grad:
+                raise NotImplementedError("fsw_gnn_amd: node-parallel training is not implemented")
+            return self._forward_node_parallel(x, edge_index)
         graph = self.build_graph(edge_index, n, edge_features if self.edgefeat_dim > 0 else None)
         E = self.embed_dim
         scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
@@ -337,6 +341,69 @@ class FSW_conv(_Base):
                                   torch.cuda.current_stream(y.device).cuda_stream)
         _lib.check(rc, "fsw_conv_fused_f32")
         return next_module
+
+    def enable_node_parallel(self, group=None, enabled=True):
+        """Shard the RECIPIENT rows over the ranks of `group`: rank r runs the whole layer for rows [r*ceil(n/G), ...) --
+        CSR of its rows, projection of all senders (replicated), the fused embedding + Linear kernel -- and ONE all-gather
+        of the out_channels-wide OUTPUT rebuilds the result (4 bytes * out_channels per node instead of the embed_dim-wide
+        embedding that slice sharding has to move).  Every row is computed by the same kernel as on one GPU (the x . W2^T
+        term by a BLAS GEMM instead of the projection kernel: agreement to 1e-7).
+        Needs the configuration of the fused kernel (unit weights, first MLP module a Linear layer)."""
+        if enabled and not self._fusable():
+            raise NotImplementedError("fsw_gnn_amd: node-parallel needs the fused configuration (csrc/conv_fused.hip); use enable_slice_parallel")
+        self._node_parallel = bool(enabled)
+        self._node_parallel_group = group
+        return self
+
+    def _forward_node_parallel(self, x, edge_index, _emulate=None):
+        """_emulate = (rank, world): this rank's work without the collective (timing on a box with fewer GPUs, tools/)."""
+        import torch.distributed as dist
+        group = getattr(self, '_node_parallel_group', None)
+        world, rank = (_emulate[1], _emulate[0]) if _emulate else (dist.get_world_size(group), dist.get_rank(group))
+        n = x.shape[0]
+        per = -(-n // world)
+        r0 = min(rank * per, n)
+        nl = min(r0 + per, n) - r0
+        emb = self.fsw_embed
+        lin = self.mlp[0]
+        H = lin.out_features
+        scale = float(self.message_weight_vs_self) if self.concat_self else 1.0
+        y_all = torch.empty((world * per, H), dtype=x.dtype, device=x.device)
+        y_loc = torch.empty((per, H), dtype=x.dtype, device=x.device)
+        # modules the fused kernel absorbs (Linear + ReLU / LeakyReLU): every rank must stop at the same one
+        next_module = 2 if len(self.mlp) > 1 and isinstance(self.mlp[1], (torch.nn.LeakyReLU, torch.nn.ReLU)) else 1
+        if nl > 0:
+            src, dst = edge_index[0], edge_index[1]
+            mine = (dst >= r0) & (dst < r0 + nl)
+            graph = build_csr(dst[mine] - r0, src[mine], None, nl, n, want_invperm=True)     # nl recipient rows, n sender columns
+            wq, w2 = self._fused_weight()
+            prepared = emb.prepare(x, graph)                    # Xp of ALL senders: replicated work, no communication
+            st = prepared["stats"]
+            xl = x[r0:r0 + nl]
+            if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
+                yin = None
+                if self.concat_self:                            # x . W2^T + b of the local rows, in degree-bin order
+                    yin = torch.addmm(lin.bias, xl, w2.t()) if lin.bias is not None else xl @ w2.t()
+                    yin = yin.index_select(0, graph.perm.long())
+                assert self._fused_linear(graph, prepared, scale, wq, yin, y_loc[:nl]) == next_module
+            else:                                               # long rows: unfused kernels on the local rows
+                E = self.embed_dim
+                buf = torch.empty((nl, E + self.in_channels if self.concat_self else E), dtype=x.dtype, device=x.device)
+                emb.embed_into(x, graph, buf, out_scale=scale, prepared=prepared)
+                if self.concat_self:
+                    buf[:, E:].copy_(xl)
+                h = lin(buf)
+                y_loc[:nl].copy_(self.mlp[1](h) if next_module == 2 else h)
+        if nl < per:
+            y_loc[nl:].zero_()
+        if _emulate:
+            y_all[rank * per:(rank + 1) * per].copy_(y_loc)
+        else:
+            dist.all_gather_into_tensor(y_all, y_loc, group=group)
+        y = y_all[:n]
+        for m in self.mlp[next_module:]:
+            y = m(y)
+        return self.bn_final(y) if self.bn_final is not None else y
 
     def enable_slice_parallel(self, group=None, enabled=True):
         """Shard the slice axis of the embedding over the ranks of `group` (dist.py); one all-gather per forward."""

@@ -733,6 +733,21 @@ with torch.no_grad():
 torch.cuda.synchronize()
 assert torch.equal(y, ref_u), float((y - ref_u).abs().max())      # no reduction anywhere: bit-identical to one GPU
 assert float((y - ref).abs().max()) < 1e-5
+# node-range sharding: every rank runs the fused layer on its rows, one all-gather of the OUTPUT
+conv.enable_slice_parallel(None, enabled=False)
+conv.fuse_linear = True
+conv.enable_node_parallel(None)
+with torch.no_grad():
+    yn = conv(X, ei)
+    # a graph with long rows: the ranks owning them fall back to the unfused kernels for their block
+    ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
+                     torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
+    yn2 = conv(X, ei2)
+    conv.enable_node_parallel(None, enabled=False)
+    ref2 = conv(X, ei2)
+torch.cuda.synchronize()
+assert float((yn - ref).abs().max()) < 2e-6 * float(ref.abs().max())     # same kernel on the same rows; only x . W2^T comes from a BLAS GEMM here
+assert float((yn2 - ref2).abs().max()) < 2e-5 * float(ref2.abs().max())
 dist.barrier()
 if rank == 0:
     print("DIST_OK")
@@ -741,7 +756,8 @@ if rank == 0:
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_slice_parallel_conv_matches_single_gpu(dev, world, tmp_path):
-    """FSW_conv.enable_slice_parallel over `world` ranks (gloo, ranks sharing the one GPU of the test box)."""
+    """FSW_conv.enable_slice_parallel and enable_node_parallel over `world` ranks (gloo, ranks sharing the one GPU of the
+    test box)."""
     import os
     import subprocess
     import sys
