@@ -538,6 +538,39 @@ def test_backward_long_rows_lds_and_global_paths(dev):
         assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
 
 
+def test_hub_row_with_100k_neighbours_forward_and_backward(dev):
+    """A star: 100 000 leaves send to vertex 0 (64 register-sorted chunks, six merge levels over the scratch line), a
+    second row of 9 000; unit and general weights; forward against the C oracle, gradients against the oracle's analytic
+    backward with the same float32 projection."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(31)
+    sizes = [100_000, 9_000]
+    n, d, S = sum(sizes) + 2, 6, 10
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=91)
+    fr = cases.random_freqs(S, seed=92)
+    rec = np.repeat(np.arange(2), sizes).astype(np.int64)
+    snd = (2 + np.arange(sum(sizes))).astype(np.int64)
+    wts = (rng.random(rec.size) + 0.1).astype(np.float32)
+    rowptr = np.concatenate([[0], np.cumsum(sizes), [sum(sizes)] * (n - 2)])
+    R = rng.standard_normal((n, S))
+    R[2:] = 0.0
+    for weights in (None, wts):
+        E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+        Xd = t(X, dev).requires_grad_(True)
+        graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), n, n)
+        assert graph.stats()[5] == 2 and graph.stats()[1] == 100_000
+        out = E.embed_autograd(Xd, graph)
+        (out * t(R, dev)).sum().backward()
+        ref = C.embed(X, rowptr, snd, weights, V, fr)
+        assert relerr(out.detach().cpu().numpy()[:2], ref[:2]) < TOL and float(out.detach()[2:].abs().max()) == 0.0
+        wv = np.ones(rec.size) if weights is None else weights.astype(np.float64)
+        gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, snd, wv, V, fr, R, Xp_override=_hip_projection(E, Xd))
+        assert relerr(Xd.grad.cpu().numpy(), gX) < 2e-5
+        assert relerr(E.projVecs.grad.cpu().numpy(), gV) < 2e-5
+        assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
+
+
 def test_backward_conv10k_training_step(dev):
     gg = golden("grads_conv10k")
     c = cases.conv10k()
