@@ -373,9 +373,10 @@ class FSW_conv(_Base):
         # modules the fused kernel absorbs (Linear + ReLU / LeakyReLU): every rank must stop at the same one
         next_module = 2 if len(self.mlp) > 1 and isinstance(self.mlp[1], (torch.nn.LeakyReLU, torch.nn.ReLU)) else 1
         if nl > 0:
-            src, dst = edge_index[0], edge_index[1]
-            mine = (dst >= r0) & (dst < r0 + nl)
-            graph = build_csr(dst[mine] - r0, src[mine], None, nl, n, want_invperm=True)     # nl recipient rows, n sender columns
+            rel = edge_index[1] - r0
+            mine = torch.nonzero((rel >= 0) & (rel < nl)).squeeze(1)                        # one compaction for both endpoints
+            sub = edge_index.index_select(1, mine)
+            graph = build_csr(sub[1] - r0, sub[0], None, nl, n, want_invperm=True)          # nl recipient rows, n sender columns
             wq, w2 = self._fused_weight()
             prepared = emb.prepare(x, graph)                    # Xp of ALL senders: replicated work, no communication
             st = prepared["stats"]
