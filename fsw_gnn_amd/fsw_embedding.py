@@ -50,14 +50,15 @@ class _EmbedGraphFn(torch.autograd.Function):
     GEMMs.  Replaces the reference's chain of sparse autograd Functions (fsw_embedding.py:1232-2257).
     Every weight mode and degree class is supported (unit-weight register rows use the float64 coefficient tables, weighted
     rows and rows above 32 neighbours evaluate the coefficients in float64 on the fly); the weights themselves are
-    constants (no gradient w.r.t. W) and total_mass_encoding_method must be 'plain'.
+    constants (no gradient w.r.t. W); the 'homog' mass encodings are differentiated by embed_autograd on top of this.
     """
 
     @staticmethod
     def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale):
         with torch.no_grad():
-            if module.encode_total_mass and module.total_mass_encoding_method != 'plain':
-                raise NotImplementedError("fsw_gnn_amd: backward supports total_mass_encoding_method='plain' only")
+            # 'homog' / 'homog_alt': embed_autograd asks for the 'plain' embedding (module._force_plain) and applies the
+            # epilogue with differentiable torch ops on top of it
+            assert (not module.encode_total_mass) or module.total_mass_encoding_method == 'plain' or module._force_plain
             prepared = module.prepare(X, graph)
             out = torch.empty((graph.num_rows, module.d_out), dtype=X.dtype, device=X.device)
             module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
@@ -432,10 +433,29 @@ class FSW_embedding(nn.Module):
         feature tensor the graph was coalesced from (its gradient is routed back through graph.slot_of_edge)."""
         bias = self.bias if self.enable_bias else None
         scale = self.total_mass_encoding_scale if self.encode_total_mass else None
-        return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale)
+        if (not self.encode_total_mass) or self.total_mass_encoding_method == 'plain':
+            return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale)
+        # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): the 'plain' embedding without bias from the
+        # kernels, then the same epilogue as embed_into(), out of place so that autograd differentiates it
+        self._force_plain = True
+        try:
+            P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale)
+        finally:
+            self._force_plain = False
+        tm = P[:, 0:1] / out_scale
+        emb = P[:, 1:]
+        norm = emb.abs().mean(dim=-1, keepdim=True) / out_scale
+        if self.total_mass_encoding_method == 'homog':
+            col0 = out_scale * tm * norm
+        else:
+            col0 = out_scale * torch.where(tm <= 1, tm * (2 - tm), torch.ones_like(tm)) * norm
+            emb = emb * torch.where(tm <= 1, tm.square(), 2 * tm - 1)
+        out = torch.cat([col0, emb], dim=1)
+        return out + out_scale * bias if bias is not None else out
 
     # ------------------------------------------------------------------------------------------------
     _slice_offset = 0   # first slice of the block being processed (slice sharding / serialize_num_slices)
+    _force_plain = False   # embed_autograd: 'plain' mass column and no bias from the kernels, epilogue in torch
 
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):
         """Projection of all slices + (unit weights) coefficient table + the one device->host stats read.
@@ -534,10 +554,10 @@ class FSW_embedding(nn.Module):
         if self.nSlices == 0:
             raise NotImplementedError("fsw_gnn_amd: nSlices == 0 with encode_total_mass is not supported")
         method = self.total_mass_encoding_method
-        plain = (not self.encode_total_mass) or method == 'plain'
+        plain = (not self.encode_total_mass) or method == 'plain' or self._force_plain
         if partial and not plain:
             raise NotImplementedError("slice sharding supports total_mass_encoding_method='plain' only")
-        bias = self.bias.detach() if (self.enable_bias and plain) else None
+        bias = self.bias.detach() if (self.enable_bias and plain and not self._force_plain) else None
         if bias is not None and partial:
             bias = torch.cat([bias[:has_mass], bias[has_mass + ka:has_mass + kb]])
         unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0

@@ -234,6 +234,33 @@ def case_grads(emb, conv):
          gb=C.mlp[0].bias.grad.numpy())
 
 
+def case_grads_homog(emb, conv):
+    """Backward goldens for total_mass_encoding_method 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144):
+    same tiny graph and cotangent as grads_tiny, weighted adjacency (masses on both sides of 1 after the 0.7 scale)."""
+    g = np.load(os.path.join(GOLD, "tiny_graph.npz"))
+    gt = np.load(os.path.join(GOLD, "grads_tiny.npz"))
+    dt = torch.float64
+    n, d, S = 64, 8, 16
+    X0, V, fr, bias, ei, R = g["X"], g["V"], gt["freqs"], g["bias"], g["edge_index"], gt["R"]
+    adj, _, _ = conv.FSW_conv.edge_index_to_adj(torch.from_numpy(ei), None, n, 0, dt)
+    adj3 = torch.sparse_coo_tensor(adj.indices(), torch.from_numpy(g["adj3_values"]), adj.shape).coalesce()
+    arrays = {}
+    for method in ("homog", "homog_alt"):
+        for tag, A in (("unit", adj), ("weighted", adj3)):
+            Em = emb.FSW_embedding(d_in=d, d_out=S + 1, encode_total_mass=True, total_mass_encoding_scale=0.7,
+                                   total_mass_encoding_method=method, learnable_slices=True, learnable_freqs=True,
+                                   learnable_total_mass_encoding_scale=True, device="cpu", dtype=dt, load_custom_cuda_lib=False)
+            set_params(Em, V, fr, bias=bias, scale=0.7)
+            X = T(X0, dt).requires_grad_(True)
+            out = Em(X, A, graph_mode=True)
+            (out * torch.from_numpy(R)).sum().backward()
+            k = method + "_" + tag
+            arrays.update({"out_" + k: out.detach().numpy(), "gX_" + k: X.grad.numpy(), "gV_" + k: Em.projVecs.grad.numpy(),
+                           "gfreqs_" + k: Em.freqs.grad.numpy(), "gbias_" + k: Em.bias.grad.numpy(),
+                           "gscale_" + k: np.array(float(Em.total_mass_encoding_scale.grad))})
+    save("grads_homog", **arrays)
+
+
 def case_edgefeat(emb, conv):
     """Edge features (reference fsw_embedding.py:934-968, fsw_conv.py:419-439): FSW_conv with edgefeat_dim = 3 on
     the tiny multigraph (duplicate edges: the reference sums their features and weights in coalesce()), forward and
@@ -325,6 +352,8 @@ def main():
         case_rmat(emb, conv)
     elif what == "grads":
         case_grads(emb, conv)
+    elif what == "grads_homog":
+        case_grads_homog(emb, conv)
     elif what == "coherence":
         case_coherence(emb)
     elif what == "edgefeat":
@@ -332,7 +361,7 @@ def main():
     elif what == "er1m":
         timings.update(case_er1m(emb, conv))
     else:
-        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|coherence|edgefeat|er1m]")
+        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|grads_homog|coherence|edgefeat|er1m]")
     json.dump(timings, open(timings_path, "w"), indent=1, sort_keys=True)
 
 

@@ -508,6 +508,37 @@ def test_backward_tiny_graph_vs_reference_autograd(dev):
         E(X2, adj3.to_dense().requires_grad_(True), graph_mode=True)
 
 
+@pytest.mark.parametrize("method", ["homog", "homog_alt"])
+def test_backward_homog_mass_encodings_vs_reference_autograd(dev, method):
+    """total_mass_encoding_method 'homog' / 'homog_alt' under autograd (reference fsw_embedding.py:874-882, 1136-1144):
+    forward and every gradient against the reference's float64 autograd (tests/golden/grads_homog.npz)."""
+    from fsw_gnn_amd import build_csr
+    g, gt, gh = golden("tiny_graph"), golden("grads_tiny"), golden("grads_homog")
+    ei = g["edge_index"]
+    E = make_embedding(dev, g["V"], gt["freqs"], bias=g["bias"], scale=0.7, encode_total_mass=True, total_mass_encoding_scale=0.7,
+                       total_mass_encoding_method=method, learnable_slices=True, learnable_freqs=True,
+                       learnable_total_mass_encoding_scale=True)
+    R = t(gt["R"], dev)
+    for tag in ("unit", "weighted"):
+        E.zero_grad()
+        X = t(g["X"], dev).requires_grad_(True)
+        if tag == "unit":
+            out = E.embed_autograd(X, build_csr(t(ei[1], dev, torch.int64), t(ei[0], dev, torch.int64), None, 64, 64))
+        else:
+            out = E(X, sparse_adj(g["adj_indices"], g["adj3_values"], (64, 64), dev), graph_mode=True)
+        k = method + "_" + tag
+        assert relerr(out.detach().cpu().numpy(), gh["out_" + k]) < TOL
+        with torch.no_grad():                                               # the inference path applies the same epilogue in place
+            assert relerr(E(X.detach(), sparse_adj(g["adj_indices"], g["adj_values"] if tag == "unit" else g["adj3_values"], (64, 64), dev),
+                            graph_mode=True).cpu().numpy(), gh["out_" + k]) < TOL
+        (out * R).sum().backward()
+        assert relerr(X.grad.cpu().numpy(), gh["gX_" + k]) < 2e-5
+        assert relerr(E.projVecs.grad.cpu().numpy(), gh["gV_" + k]) < 2e-5
+        assert relerr(E.freqs.grad.cpu().numpy(), gh["gfreqs_" + k]) < 2e-5
+        assert relerr(E.bias.grad.cpu().numpy(), gh["gbias_" + k]) < 1e-6
+        assert abs(float(E.total_mass_encoding_scale.grad) - float(gh["gscale_" + k])) < 2e-5 * abs(float(gh["gscale_" + k]))
+
+
 def test_backward_long_rows_lds_and_global_paths(dev):
     """Readout-shaped input (segments of 700 / 3000 / 5000 points), unit and weighted: LDS and global backward kernels
     against the oracle's analytic backward evaluated with the same float32 sort order."""
