@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
     const int Dtot = WEIGHTED ? D + 1 : D;
-    IndexedNet<DP> net;
+    U64Net<DP> net;
     double m = (double)D;
     if constexpr (WEIGHTED) m = 0.0;
 #pragma unroll
@@ -83,8 +83,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
       } else if (WEIGHTED && t == D) {
         key = 0.f;   // the reference's pad element at x = 0
       }
-      net.k[t] = key;
-      net.w[t] = __int_as_float(t);
+      net.e[t] = pack_key_index(key, t);
     }
     sort_network<DP>(net);
     const double inv = 1.0 / (WEIGHTED ? fmax(m, taud) : m);
@@ -103,8 +102,8 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
           c = cn;
           double F, dF;
           F_dF_sc_m(fc, (double)(r + 1) * inv, s, c, F, dF);
-          tile[__float_as_int(net.w[r]) * kWave] = gi * (float)(F - Fp);
-          gf = fmaf(gi * (float)(dF - dFp), net.k[r], gf);
+          tile[(int)(unsigned int)net.e[r] * kWave] = gi * (float)(F - Fp);
+          gf = fmaf(gi * (float)(dF - dFp), from_orderable_bits((unsigned int)(net.e[r] >> 32)), gf);
           Fp = F;
           dFp = dF;
         }
@@ -114,14 +113,14 @@ __global__ void __launch_bounds__(256) k_embed_mid_bwd(const int32_t* __restrict
 #pragma unroll
       for (int r = 0; r < DP; ++r) {
         if (r < Dtot) {
-          const int id = __float_as_int(net.w[r]);
+          const int id = (int)(unsigned int)net.e[r];
           c += (double)(id == D ? padw : (w ? w[start + id] : 1.f));
           const double ph = xi * (c * inv);
           double s, co, F, dF;
           sincospi(2.0 * (ph - rint(ph)), &s, &co);
           F_dF_sc_m(fc, c * inv, s, co, F, dF);
           if (id < D) tile[id * kWave] = gi * (float)(F - Fp);   // the pad element has no source row
-          gf = fmaf(gi * (float)(dF - dFp), net.k[r], gf);
+          gf = fmaf(gi * (float)(dF - dFp), from_orderable_bits((unsigned int)(net.e[r] >> 32)), gf);
           Fp = F;
           dFp = dF;
         }

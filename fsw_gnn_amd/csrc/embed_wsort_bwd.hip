@@ -82,7 +82,7 @@ __device__ __forceinline__ void F_dF(const FCoef& f, double c, double& F, double
 // WEIGHTED: weight_of(index) returns the element's weight, `cbase` is the cumulative weight before this lane's first
 // element on entry (only used when WEIGHTED).
 template <int M, bool WEIGHTED, class WeightFn, class EmitFn>
-__device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, int r0, int D, int Dtot, double xi, double inv, float gi,
+__device__ __forceinline__ float walk_line(const WaveLine64<M>& ln, int r0, int D, int Dtot, double xi, double inv, float gi,
                                            double cbase, WeightFn weight_of, EmitFn emit) {
   float gf = 0.f;
   double Fp, dFp;
@@ -102,8 +102,8 @@ __device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, in
       double F, dF;
       F_dF_sc(fc, (double)min(r0 + j + 1, D) * inv, s, c, F, dF);
       if (r0 + j < D) {
-        emit(__float_as_int(ln.w[j]), gi * (float)(F - Fp));
-        gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
+        emit(ln.index(j), gi * (float)(F - Fp));
+        gf = fmaf(gi * (float)(dF - dFp), ln.key(j), gf);
       }
       Fp = F;
       dFp = dF;
@@ -113,14 +113,14 @@ __device__ __forceinline__ float walk_line(const WaveLine<M, true, true>& ln, in
     F_dF(fc, c * inv, Fp, dFp);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const int id = __float_as_int(ln.w[j]);
+      const int id = ln.index(j);
       const bool valid = r0 + j < Dtot;
       c += valid ? (double)weight_of(id) : 0.0;
       double F, dF;
       F_dF(fc, c * inv, F, dF);
       if (valid) {
         if (id < D) emit(id, gi * (float)(F - Fp));   // the pad element (id == D) has no source row
-        gf = fmaf(gi * (float)(dF - dFp), ln.k[j], gf);
+        gf = fmaf(gi * (float)(dF - dFp), ln.key(j), gf);
       }
       Fp = F;
       dFp = dF;
@@ -204,13 +204,12 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
       for (int kk = wv; kk < SC; kk += 4) {
         const int k = k0 + kk;
         if (k >= S) break;
-        WaveLine<M, true, true> ln;
+        WaveLine64<M> ln;
         float* line = tile + kk * LINE;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
           const int t = lane * M + j;
-          ln.k[j] = t < Dtot ? line[lane * (M + 1) + j] : __builtin_inff();
-          ln.w[j] = __int_as_float(t);
+          ln.e[j] = pack_key_index(t < Dtot ? line[lane * (M + 1) + j] : __builtin_inff(), t);
         }
         if (!(FSW_WSB_ABL & 2)) ln.sort();
         const double xi = (double)freqs[k];
@@ -220,7 +219,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
           double part = 0.0;
 #pragma unroll
           for (int j = 0; j < M; ++j) {
-            const int id = __float_as_int(ln.w[j]);
+            const int id = ln.index(j);
             part += (lane * M + j < Dtot) ? (double)wrow[id + id / M] : 0.0;
           }
           cbase = wave_exclusive_scan_b64(part);
@@ -249,12 +248,12 @@ __global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restri
 // fences below: workgroup scope orders a wave's scratch stores before its own later loads (same CU, same L1; see embed_wsort.hip)
 constexpr int kSweepDepthB = 4;
 
-__device__ __forceinline__ void sweep_pairs_b(float* __restrict__ sk, float* __restrict__ si, int Dp, int size, int st, bool flip) {
+__device__ __forceinline__ void sweep_pairs_b(unsigned long long* __restrict__ se, int Dp, int size, int st, bool flip) {
   const int npairs = Dp >> 1;
   const int half = size >> 1;
   for (int i0 = lane_id(); i0 < npairs; i0 += kWave * kSweepDepthB) {
     int ia[kSweepDepthB], ib[kSweepDepthB];
-    float ka[kSweepDepthB], kb[kSweepDepthB], pa[kSweepDepthB], pb[kSweepDepthB];
+    unsigned long long a[kSweepDepthB], b[kSweepDepthB];
 #pragma unroll
     for (int u = 0; u < kSweepDepthB; ++u) {
       const int idx = i0 + u * kWave;
@@ -267,18 +266,14 @@ __device__ __forceinline__ void sweep_pairs_b(float* __restrict__ sk, float* __r
         ia[u] = blk * 2 * st + off;
         ib[u] = ia[u] + st;
       }
-      ka[u] = sk[ia[u]];
-      kb[u] = sk[ib[u]];
-      pa[u] = si[ia[u]];
-      pb[u] = si[ib[u]];
+      a[u] = se[ia[u]];
+      b[u] = se[ib[u]];
     }
 #pragma unroll
     for (int u = 0; u < kSweepDepthB; ++u) {
-      if (kb[u] < ka[u] || (kb[u] == ka[u] && __float_as_int(pb[u]) < __float_as_int(pa[u]))) {   // equal keys: by element index
-        sk[ia[u]] = kb[u];
-        sk[ib[u]] = ka[u];
-        si[ia[u]] = pb[u];
-        si[ib[u]] = pa[u];
+      if (b[u] < a[u]) {   // packed words: by key, equal keys by element index
+        se[ia[u]] = b[u];
+        se[ib[u]] = a[u];
       }
     }
   }
@@ -298,9 +293,8 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
   constexpr int CAP = M * kWave;
   const int lane = lane_id();
   const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
-  float* sk = reinterpret_cast<float*>(scratch + (int64_t)gw * wave_bytes);   // keys | element indices | contributions
-  float* si = sk + wave_bytes / 12;
-  float* sc = si + wave_bytes / 12;
+  unsigned long long* se = reinterpret_cast<unsigned long long*>(scratch + (int64_t)gw * wave_bytes);   // packed (key, index) words
+  float* sc = reinterpret_cast<float*>(se + wave_bytes / 12);                                           // contributions, element order
   const int pbeg = bin_start[FSW_BIN_GLOBAL], pend = bin_start[FSW_BIN_GLOBAL + 1];
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
@@ -322,7 +316,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
     const double xi = (double)freqs[k];
     const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
     for (int c0 = 0; c0 < Dp; c0 += CAP) {
-      WaveLine<M, true, true> ln;
+      WaveLine64<M> ln;
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const int t = c0 + lane * M + j;
@@ -337,46 +331,36 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
         } else if (WEIGHTED && t == D) {
           key = 0.f;
         }
-        ln.k[j] = key;
-        ln.w[j] = __int_as_float(t);
+        ln.e[j] = pack_key_index(key, t);
       }
       ln.sort();
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        sk[c0 + lane * M + j] = ln.k[j];
-        si[c0 + lane * M + j] = ln.w[j];
-      }
+      for (int j = 0; j < M; ++j) se[c0 + lane * M + j] = ln.e[j];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     float gf = 0.f;
     double carry = 0.0;
     auto weight_of = [&](int id) { return id == D ? padw : (w ? w[start + id] : 1.f); };
     for (int size = 2 * CAP; size <= Dp; size <<= 1) {
-      sweep_pairs_b(sk, si, Dp, size, 0, true);
-      for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs_b(sk, si, Dp, size, st, false);
+      sweep_pairs_b(se, Dp, size, 0, true);
+      for (int st = size >> 2; st >= CAP; st >>= 1) sweep_pairs_b(se, Dp, size, st, false);
       const bool last = size == Dp;
       for (int c0 = 0; c0 < Dp; c0 += CAP) {
         if (last && c0 >= Dtot) break;
-        WaveLine<M, true, true> ln;
+        WaveLine64<M> ln;
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-          ln.k[j] = sk[c0 + lane * M + j];
-          ln.w[j] = si[c0 + lane * M + j];
-        }
+        for (int j = 0; j < M; ++j) ln.e[j] = se[c0 + lane * M + j];
         ln.merge_chunk();
         if (!last) {
 #pragma unroll
-          for (int j = 0; j < M; ++j) {
-            sk[c0 + lane * M + j] = ln.k[j];
-            si[c0 + lane * M + j] = ln.w[j];
-          }
+          for (int j = 0; j < M; ++j) se[c0 + lane * M + j] = ln.e[j];
           continue;
         }
         double cbase = 0.0;
         if constexpr (WEIGHTED) {
           double part = 0.0;
 #pragma unroll
-          for (int j = 0; j < M; ++j) part += (c0 + lane * M + j < Dtot) ? (double)weight_of(__float_as_int(ln.w[j])) : 0.0;
+          for (int j = 0; j < M; ++j) part += (c0 + lane * M + j < Dtot) ? (double)weight_of(ln.index(j)) : 0.0;
           cbase = carry + wave_exclusive_scan_b64(part);
           carry += wave_sum_b64(part);
         }

@@ -69,6 +69,37 @@ struct IndexedNet {
   }
 };
 
+// 64-bit words (orderable key bits << 32 | element index): one unsigned compare orders by key, then index
+template <int D>
+struct U64Net {
+  unsigned long long e[D];
+  template <int I, int J>
+  FSW_HD void cx() {
+    if constexpr (J < D) {
+      const unsigned long long a = e[I], b = e[J];
+      const bool sw = b < a;
+      e[I] = sw ? b : a;
+      e[J] = sw ? a : b;
+    }
+  }
+};
+
+// float <-> uint32 with the same order (negative floats reversed, positive above them)
+FSW_HD unsigned int orderable_bits(float f) {
+  unsigned int u;
+  __builtin_memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+FSW_HD float from_orderable_bits(unsigned int o) {
+  const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+FSW_HD unsigned long long pack_key_index(float key, int idx) {
+  return ((unsigned long long)orderable_bits(key) << 32) | (unsigned int)idx;
+}
+
 template <class Net, int LO, int N, int R>
 struct OddEvenMerge {
   template <int I, int END, int STEP>

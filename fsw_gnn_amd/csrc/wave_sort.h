@@ -141,4 +141,74 @@ struct WaveLine {
   }
 };
 
+// The same line layout and merge structure for 64-bit words (pack_key_index: key, then element index): the backward
+// kernels sort these -- one unsigned 64-bit compare per pair orders by key with ties by index (= the reference's stable
+// order), and the element index comes back out of the low word.
+template <int M>
+struct WaveLine64 {
+  unsigned long long e[M];
+
+  template <int MASK>
+  static __device__ __forceinline__ unsigned long long xor_lane64(unsigned long long v) {
+    const float lo = xor_lane<MASK>(__uint_as_float((unsigned int)v));
+    const float hi = xor_lane<MASK>(__uint_as_float((unsigned int)(v >> 32)));
+    return ((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo);
+  }
+  template <int JREV, int MASK>
+  __device__ __forceinline__ void exchange(bool lower) {
+    unsigned long long o[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) o[j] = xor_lane64<MASK>(e[JREV ? M - 1 - j : j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const bool take = lower ? (o[j] < e[j]) : (o[j] > e[j]);
+      e[j] = take ? o[j] : e[j];
+    }
+  }
+  __device__ __forceinline__ void cx(int i, int j) {
+    const unsigned long long a = e[i], b = e[j];
+    const bool sw = b < a;
+    e[i] = sw ? b : a;
+    e[j] = sw ? a : b;
+  }
+  template <int ST>
+  __device__ __forceinline__ void half_cleaners(int lane) {
+    if constexpr (ST >= 1) {
+      exchange<0, ST>((lane & ST) == 0);
+      half_cleaners<(ST >> 1)>(lane);
+    }
+  }
+  __device__ __forceinline__ void in_register_cleaners() {
+#pragma unroll
+    for (int st = M >> 1; st >= 1; st >>= 1)
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if ((j & st) == 0) cx(j, j + st);
+  }
+  template <int LANES>
+  __device__ __forceinline__ void merge_levels(int lane) {
+    if constexpr (LANES <= kWave) {
+      exchange<1, LANES - 1>((lane & (LANES >> 1)) == 0);
+      half_cleaners<(LANES >> 2)>(lane);
+      in_register_cleaners();
+      merge_levels<LANES * 2>(lane);
+    }
+  }
+  __device__ __forceinline__ void sort() {
+    U64Net<M> net;
+#pragma unroll
+    for (int j = 0; j < M; ++j) net.e[j] = e[j];
+    sort_network<M>(net);
+#pragma unroll
+    for (int j = 0; j < M; ++j) e[j] = net.e[j];
+    merge_levels<2>(lane_id());
+  }
+  __device__ __forceinline__ void merge_chunk() {
+    half_cleaners<(kWave >> 1)>(lane_id());
+    in_register_cleaners();
+  }
+  __device__ __forceinline__ float key(int j) const { return from_orderable_bits((unsigned int)(e[j] >> 32)); }
+  __device__ __forceinline__ int index(int j) const { return (int)(unsigned int)e[j]; }
+};
+
 }  // namespace fsw
