@@ -130,7 +130,7 @@ __device__ __forceinline__ float walk_line(const WaveLine64<M>& ln, int r0, int 
 }
 
 template <int M, bool WEIGHTED>
-__global__ void __launch_bounds__(256) k_embed_wsort_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+__global__ void __launch_bounds__(256, (M <= 16 ? 2 : 1)) k_embed_wsort_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ w, const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi,
                                                          const float* __restrict__ Xp, int64_t ldp, int S,
