@@ -22,7 +22,10 @@
 namespace fsw {
 
 constexpr double kPiB = 3.14159265358979323846;
-constexpr int kWbLdsBytes = 69 * 1024;
+// LDS per workgroup: two workgroups per CU, except where the registers of a wave (one wave per SIMD) already allow only one
+// workgroup per CU -- those instances take twice the lines per slice group, i.e. twice as long atomic runs per neighbour
+template <int M, bool WEIGHTED>
+constexpr int wb_lds_bytes() { return (WEIGHTED ? M >= 64 : M >= 32) ? 140 * 1024 : 69 * 1024; }
 constexpr int kWbSplitY = 4;
 #ifndef FSW_WSB_ABL
 #define FSW_WSB_ABL 0   // timing experiments on k_embed_wsort_bwd: 1 no atomics, 2 no sort, 4 no coefficient walk
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(256, (M <= 16 ? 2 : 1)) k_embed_wsort_bwd(cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wrow = smem;                                   // [LINE] weights of the row, padded like a line (weighted only)
   float* tile = smem + (WEIGHTED ? LINE : 0);           // [SC][LINE]
-  constexpr int kTileLines = (kWbLdsBytes / 4 - (WEIGHTED ? LINE : 0)) / LINE;
+  constexpr int kTileLines = (wb_lds_bytes<M, WEIGHTED>() / 4 - (WEIGHTED ? LINE : 0)) / LINE;
   static_assert(kTileLines >= 1, "a line must fit the LDS budget");
   constexpr int SC = kTileLines >= 64 ? 64 : (kTileLines >= 4 ? (kTileLines & ~3) : kTileLines);
   __shared__ double msum[4];
@@ -395,11 +398,11 @@ static int launch_wsort_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int
   static bool attr_set = false;
   if (!attr_set) {
     FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_wsort_bwd<M, WEIGHTED>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWbLdsBytes));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, wb_lds_bytes<M, WEIGHTED>()));
     attr_set = true;
   }
   dim3 grid((unsigned)std::min<int64_t>(rows_upper, 1 << 14), kWbSplitY);
-  k_embed_wsort_bwd<M, WEIGHTED><<<grid, 256, kWbLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp,
+  k_embed_wsort_bwd<M, WEIGHTED><<<grid, 256, wb_lds_bytes<M, WEIGHTED>(), stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp,
                                                                    a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq,
                                                                    a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk);
   FSW_LAUNCH_CHECK();
