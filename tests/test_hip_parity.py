@@ -474,6 +474,19 @@ def _hip_projection(E, X):
         return E.prepare(X.detach().contiguous(), build_csr(idx, idx, None, n, n))["Xp"][:, :E.nSlices].cpu().numpy()
 
 
+def _hip_projection_cols(E, X, d):
+    """float32 X . projVecs[:, :d]^T from the kernel under test (module with edge features: vertex part of the slices)."""
+    from fsw_gnn_amd import _lib
+    L = _lib.lib()
+    Xc = X.detach().contiguous()
+    n, S = Xc.shape[0], E.nSlices
+    V = E.projVecs.detach()
+    Xp = torch.empty((n, (S + 63) // 64 * 64), dtype=torch.float32, device=Xc.device)
+    _lib.check(L.fsw_project_f32(Xc.data_ptr(), n, d, d, V.data_ptr(), S, V.stride(0), Xp.data_ptr(), Xp.stride(0), None, 0, None,
+                                 torch.cuda.current_stream(Xc.device).cuda_stream), "project")
+    return Xp[:, :S].cpu().numpy().astype(np.float64)
+
+
 def test_backward_tiny_graph_vs_reference_autograd(dev):
     """Gradients of the HIP backward kernel against the reference's own autograd (float64 goldens)."""
     from fsw_gnn_amd import build_csr
@@ -744,6 +757,21 @@ def test_edge_features_embedding_sparse_inputs_and_long_rows(dev):
     ref = O.fsw_embedding_forward(X, rowptr, src, wv, V, fr, edge_feat=ef)
     assert np.diff(rowptr)[:4].tolist() == [300, 60, 150, 2500]
     assert relerr(out, ref) < TOL and relerr(out[:4], ref[:4]) < TOL
+    # backward through the key-gradient form of every long-row kernel (gradients for X, both parts of projVecs, freqs).
+    # The oracle sorts with the float32 keys of the path under test up to the rounding of the edge term; a rare near-tie
+    # swap between the two moves a small amount of gradient between two entries, hence the looser bound.
+    E2 = make_embedding(dev, V[:, :d], fr, enable_bias=False, d_edge=de, learnable_slices=True, learnable_freqs=True)
+    with torch.no_grad():
+        E2.projVecs.copy_(t(V, dev))
+    Xd = t(X, dev).requires_grad_(True)
+    R = rng.standard_normal((n, S))
+    R[4:] *= 0.05                                               # weight the long rows
+    (E2(Xd, W, Xe, graph_mode=True) * t(R, dev)).sum().backward()
+    keys = (_hip_projection_cols(E2, Xd, d)[src] + ef.astype(np.float64) @ V[:, d:].astype(np.float64).T).astype(np.float32)
+    gX, gV, gxi, _ = O.fsw_embed_csr_backward(X, rowptr, src, wv, V, fr, R, edge_feat=ef, keys_override=keys)
+    assert relerr(Xd.grad.cpu().numpy(), gX) < 1e-3
+    assert relerr(E2.projVecs.grad.cpu().numpy(), gV) < 1e-3
+    assert relerr(E2.freqs.grad.cpu().numpy(), gxi) < 1e-3
     m = 400                                                  # dense W / X_edge on a sub-block (dense n x n x de would be 54 MB)
     keep = (dst < m) & (src < m)
     with torch.no_grad():
