@@ -23,6 +23,14 @@ def slice_partition(num_slices, world_size):
     return out
 
 
+def node_block(num_rows, world_size, rank):
+    """Recipient-row sharding (FSW_conv.enable_node_parallel): rank r owns rows [r0, r0 + nl) of equal-size blocks of
+    per = ceil(num_rows / world_size) rows (the last blocks may be short or empty).  Returns (per, r0, nl)."""
+    per = -(-num_rows // world_size)
+    r0 = min(rank * per, num_rows)
+    return per, r0, min(r0 + per, num_rows) - r0
+
+
 def all_gather_slice_blocks(local, parts, has_mass, out, group=None):
     """local [n, has_mass + max_width] of this rank -> out[:, :has_mass + S] on every rank.
 

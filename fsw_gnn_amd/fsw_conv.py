@@ -360,10 +360,9 @@ class FSW_conv(_Base):
         import torch.distributed as dist
         group = getattr(self, '_node_parallel_group', None)
         world, rank = (_emulate[1], _emulate[0]) if _emulate else (dist.get_world_size(group), dist.get_rank(group))
+        from .dist import node_block
         n = x.shape[0]
-        per = -(-n // world)
-        r0 = min(rank * per, n)
-        nl = min(r0 + per, n) - r0
+        per, r0, nl = node_block(n, world, rank)
         emb = self.fsw_embed
         lin = self.mlp[0]
         H = lin.out_features

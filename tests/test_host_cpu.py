@@ -168,3 +168,16 @@ def test_coherence_minimisation_matches_reference():
     assert C.fsw_embed.minimize_slice_coherence
     rnd = torch.nn.functional.normalize(torch.randn(19, 6, dtype=torch.float64), dim=1)
     assert float(mutual_coherence(C.fsw_embed.projVecs.detach().double())) < float(mutual_coherence(rnd))
+
+
+def test_node_block_partition_covers_every_row_once():
+    from fsw_gnn_amd.dist import node_block
+    for n, world in ((1_000_000, 8), (10, 4), (3, 8), (7, 7), (1, 2)):
+        blocks = [node_block(n, world, r) for r in range(world)]
+        per = blocks[0][0]
+        assert all(b[0] == per for b in blocks) and per * world >= n
+        covered = []
+        for _, r0, nl in blocks:
+            assert 0 <= nl <= per
+            covered += list(range(r0, r0 + nl))
+        assert covered == list(range(n))
