@@ -153,10 +153,13 @@ typedef struct {
   int32_t has_mass;  /* 1: column 0 of out carries the encoded total mass */
   int32_t mass_fn;   /* 0 identity, 1 sqrt: 2m/(sqrt(m+1)+1), 2 log1p      (fsw_embedding.py:857-865) */
   float mass_scale;
-  /* row counts per path, host values read back from stats; -1 = unknown (launch every path) */
+  /* row counts per path, host values read back from stats (num_lds_rows = stats[FSW_STAT_NUM_LDS]: every row of
+   * FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG, the library picks the kernel per degree bin); -1 = unknown (launch
+   * every path) */
   int64_t num_reg_rows, num_lds_rows, num_global_rows, num_zero_rows;
   int64_t max_degree; /* host value of stats[FSW_STAT_MAX_DEGREE]; required when num_global_rows != 0 */
-  /* scratch for the global path: >= fsw_embed_scratch_bytes() or NULL if num_global_rows == 0 */
+  /* scratch for rows above FSW_LDS_MAX_DEG (sorted in a scratch line per wavefront, any degree): at least
+   * fsw_embed_scratch_bytes(max_degree) bytes, or NULL if num_global_rows == 0 */
   void* scratch;
   size_t scratch_bytes;
   /* edge features (reference fsw_embedding.py:934-968): the key of CSR entry e of slice k is
