@@ -97,6 +97,7 @@ FSW_HD float from_orderable_bits(unsigned int o) {
   return f;
 }
 FSW_HD unsigned long long pack_key_index(float key, int idx) {
+  if (key == 0.f) key = 0.f;   // -0 and +0 are equal keys: both map to +0 so that only the index orders them
   return ((unsigned long long)orderable_bits(key) << 32) | (unsigned int)idx;
 }
 
