@@ -10,18 +10,22 @@ from fsw_gnn_amd import FSW_conv, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--rmat", type=int, default=0)
 ap.add_argument("--forward-only", action="store_true")
+ap.add_argument("--edges", type=int, default=bench.N_EDGES)
+ap.add_argument("--feat", type=int, default=128)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-n, E = bench.N_NODES, bench.N_EDGES
+n, E = bench.N_NODES, args.edges
 if args.rmat:
     n = 1 << args.rmat
     ei = torch.from_numpy(synth.rmat_graph(args.rmat, E, 7)).to(dev)
-    x = torch.from_numpy(synth.features(n, 128, 3)).to(dev)
+    x = torch.from_numpy(synth.features(n, args.feat, 3)).to(dev)
 else:
     x, ei = bench.make_inputs(n, E, dev)
-conv = FSW_conv(128, 128, embed_dim=257, device=dev)
+    assert args.feat == 128
+conv = FSW_conv(args.feat, 128, embed_dim=257, device=dev)
 with torch.no_grad():
-    print("inference forward, %d nodes / %d edges / 256 slices: %.2f ms" % (n, E, bench.timed_ms(lambda: conv(x, ei), 5, dev)), flush=True)
+    print("inference forward, %d nodes / %d edges / %d feat / 256 slices: %.2f ms (max in-degree %d)" % (
+        n, E, args.feat, bench.timed_ms(lambda: conv(x, ei), 5, dev), int(torch.bincount(ei[1]).max())), flush=True)
 if not args.forward_only:
     x.requires_grad_(True)
     def step():
