@@ -59,12 +59,13 @@ __global__ void __launch_bounds__(256) k_unit_table(const float* __restrict__ fr
 __global__ void __launch_bounds__(256) k_zero_rows(const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
                                                    int S, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
                                                    float out_scale, int has_mass) {
-  const int n0 = bin_start[1] - bin_start[0];
+  // one wavefront per row, lanes along the columns: contiguous stores, no integer division per element
+  const int p0 = bin_start[0], n0 = bin_start[1] - p0;
   const int width = S + has_mass;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n0 * width; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = perm[bin_start[0] + (int)(i / width)];
-    const int c = (int)(i % width);
-    out[(int64_t)r * ldo + c] = bias ? out_scale * bias[c] : 0.f;
+  const int wave = blockIdx.x * (blockDim.x / kWave) + wave_id(), nwaves = gridDim.x * (blockDim.x / kWave);
+  for (int i = wave; i < n0; i += nwaves) {
+    float* orow = out + (int64_t)perm[p0 + i] * ldo;
+    for (int c = lane_id(); c < width; c += kWave) orow[c] = bias ? out_scale * bias[c] : 0.f;
   }
 }
 
