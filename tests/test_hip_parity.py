@@ -345,6 +345,46 @@ def test_mid_degree_rows_backward(dev):
         assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_random_mix_of_degree_classes(dev, seed):
+    """Randomised cases: every row draws its in-degree from a mix that touches all degree classes (0, 1..32, the padded
+    networks, the three wave-sort classes, the chunked path), random slice counts incl. 1 and non-multiples of 64, random
+    choice of unit / general weights, total-mass column and bias; forward against the numpy oracle."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(seed)
+    pool = np.concatenate([np.arange(0, 41), [48, 49, 64, 65, 100, 128, 129, 200, 256, 257, 511, 512, 513, 1024, 1025, 2048, 2049, 4097]])
+    nrows = 60
+    deg = rng.choice(pool, size=nrows)
+    deg[rng.integers(0, nrows, 3)] = rng.choice([2049, 3000, 4097], size=3)
+    n = int(max(deg.max(), 300)) + 10
+    d = int(rng.choice([3, 8, 17]))
+    S = int(rng.choice([1, 7, 64, 65, 130]))
+    weighted = bool(rng.integers(0, 2))
+    mass = bool(rng.integers(0, 2))
+    use_bias = bool(rng.integers(0, 2))
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=seed)
+    fr = cases.random_freqs(S, seed=seed + 1)
+    if S > 2 and rng.integers(0, 2):
+        fr[0] = 0.0
+    rec = np.repeat(np.arange(nrows), deg).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in deg] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    w = (rng.random(rec.size) * 0.2 + 0.001).astype(np.float32) if weighted else None      # many rows below tau = 1: pad element
+    bias = rng.standard_normal(S + (1 if mass else 0)).astype(np.float32) if use_bias else None
+    order = rng.permutation(rec.size)
+    E = make_embedding(dev, V, fr, bias=bias, scale=1.3 if mass else None, encode_total_mass=mass, enable_bias=use_bias)
+    with torch.no_grad():
+        graph = build_csr(t(rec[order], dev, torch.int64), t(snd[order], dev, torch.int64), None if w is None else t(w[order], dev), nrows, n)
+        out = torch.empty((nrows, S + (1 if mass else 0)), device=dev)
+        E.embed_into(t(X, dev), graph, out)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if w is None else w.astype(np.float64), V, fr, bias=bias,
+                                  encode_total_mass=mass, total_mass_encoding_scale=1.3)
+    got = out.cpu().numpy()
+    assert relerr(got, ref) < TOL, (seed, S, d, weighted, mass, use_bias)
+    assert np.abs(got - ref).max() < 3e-5 * max(np.abs(ref).max(), 1e-3)
+
+
 def test_readout_layer(dev):
     from fsw_gnn_amd import FSW_readout
     rng = np.random.default_rng(4)
