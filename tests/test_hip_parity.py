@@ -385,6 +385,40 @@ def test_random_mix_of_degree_classes(dev, seed):
     assert np.abs(got - ref).max() < 3e-5 * max(np.abs(ref).max(), 1e-3)
 
 
+@pytest.mark.parametrize("seed", [201, 202, 203, 204])
+def test_random_mix_of_degree_classes_backward(dev, seed):
+    """The same kind of random mix through the backward kernels (register, lane-per-slice, wave-sort, chunked scratch
+    paths in one graph) against the oracle's analytic backward with the float32 projection of the path under test."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(seed)
+    pool = np.concatenate([np.arange(0, 41), [48, 64, 65, 100, 128, 129, 200, 256, 257, 512, 513, 1024, 1025, 2048, 2049]])
+    nrows = 40
+    deg = rng.choice(pool, size=nrows)
+    deg[rng.integers(0, nrows, 2)] = rng.choice([2049, 3000, 4097], size=2)
+    n = int(max(deg.max(), 300)) + 10
+    d, S = int(rng.choice([4, 9])), int(rng.choice([5, 33, 70]))
+    weighted = bool(seed % 2)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=seed)
+    fr = cases.random_freqs(S, seed=seed + 1)
+    rec = np.repeat(np.arange(nrows), deg).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in deg]).astype(np.int64)
+    w = (rng.random(rec.size) * 0.2 + 0.001).astype(np.float32) if weighted else None
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    R = rng.standard_normal((nrows, S))
+    E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+    Xd = t(X, dev).requires_grad_(True)
+    graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if w is None else t(w, dev), nrows, n)
+    out = E.embed_autograd(Xd, graph)
+    (out * t(R, dev)).sum().backward()
+    wv = np.ones(rec.size) if w is None else w.astype(np.float64)
+    assert relerr(out.detach().cpu().numpy(), O.fsw_embedding_forward(X, rowptr, snd, wv, V, fr)) < TOL
+    gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, snd, wv, V, fr, R, Xp_override=_hip_projection(E, Xd))
+    assert relerr(Xd.grad.cpu().numpy(), gX) < 3e-5, (seed, S, d, weighted)
+    assert relerr(E.projVecs.grad.cpu().numpy(), gV) < 3e-5
+    assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 3e-5
+
+
 def test_readout_layer(dev):
     from fsw_gnn_amd import FSW_readout
     rng = np.random.default_rng(4)
