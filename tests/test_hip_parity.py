@@ -419,6 +419,29 @@ def test_random_mix_of_degree_classes_backward(dev, seed):
     assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 3e-5
 
 
+def test_degenerate_graphs(dev):
+    """No edges at all, a single vertex, a single self loop, every edge into one vertex: the layer must run and match
+    what the oracle says about rows without neighbours (zero embedding, mass 0) and about the rest."""
+    from fsw_gnn_amd import FSW_conv
+    torch.manual_seed(11)
+    d, out_ch, embed_dim = 6, 5, 9
+    conv = FSW_conv(d, out_ch, embed_dim=embed_dim, device=dev)
+    V = conv.fsw_embed.projVecs.detach().cpu().numpy()
+    fr = conv.fsw_embed.freqs.detach().cpu().numpy()
+    lw, lb = conv.mlp[0].weight.detach().cpu().numpy().astype(np.float64), conv.mlp[0].bias.detach().cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(12)
+    for n, edges in ((5, np.zeros((2, 0), dtype=np.int64)), (1, np.zeros((2, 0), dtype=np.int64)), (1, np.array([[0], [0]])),
+                     (40, np.stack([np.arange(40), np.full(40, 7)]))):
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        with torch.no_grad():
+            y = conv(t(X, dev), t(edges, dev, torch.int64)).cpu().numpy()
+        order = np.argsort(edges[1], kind="stable")
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(edges[1], minlength=n))])
+        emb = O.fsw_embedding_forward(X, rowptr, edges[0][order], np.ones(edges.shape[1]), V, fr, encode_total_mass=True)
+        ref = O.conv_tail(emb, X.astype(np.float64), linear_weight=lw, linear_bias=lb)
+        assert y.shape == (n, out_ch) and relerr(y, ref) < 1e-5 and np.isfinite(y).all()
+
+
 def test_readout_layer(dev):
     from fsw_gnn_amd import FSW_readout
     rng = np.random.default_rng(4)
