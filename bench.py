@@ -9,8 +9,13 @@ column, 'spread' frequencies, one Linear + LeakyReLU layer -- synthetic data, ra
 A step is ONE full FSW_conv.forward(x, edge_index): CSR build from the int64 edge_index (rebuilt every step like
 the reference, fsw_conv.py:352 -- nothing is cached), fp32-MFMA projection, fused neighbourhood sort / cumulative
 sum / Fourier readout, concat with the vertex features and the Linear layer.  Inputs are resident in HBM before
-the timed region.  With N > 1 the slice axis is sharded over the ranks (256 / N slices each, total work fixed ->
-strong scaling) and reassembled by one RCCL all-gather.
+the timed region.  With N > 1 the SLICE axis is sharded over the ranks (BASELINE north_star; 256 / N slices each, total
+work fixed -> strong scaling): by default the sharded-consumer form of fsw_gnn_amd/dist.py (every rank multiplies its
+slice block by its columns of the first Linear layer inside the fused kernel, the n x 128 partial sums are
+reduce-scattered, finished rows all-gathered, node-range chunks pipelined); --mode gather runs the contracted
+all-gather of the embedding instead.  The line then also carries compute_ms (the same step with the collectives
+replaced by local copies), collective_ms / collective_GBps (the step's collectives alone on same-size buffers) and
+bytes per rank.  --shard nodes (recipient-row sharding, not the contracted partition) stays behind its flag.
 
 The JSON line also carries
   roofline     the dominant kernel (k_conv_fused_unit; k_embed_reg_unit with --no-fuse) timed alone, HIP events on the launch stream:
@@ -49,9 +54,14 @@ def parse():
     ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
-    ap.add_argument("--shard", choices=("nodes", "slices"), default="nodes",
-                    help="N > 1: 'nodes' = every rank runs the fused layer on its block of recipient rows, all-gather of the "
-                         "128-wide output; 'slices' = BASELINE north_star's slice-axis shard, all-gather of the 257-wide embedding")
+    ap.add_argument("--shard", choices=("slices", "nodes"), default="slices",
+                    help="N > 1: 'slices' = BASELINE north_star's slice-axis shard (default); 'nodes' = every rank runs the fused "
+                         "layer on its block of recipient rows, all-gather of the 128-wide output (extra, not the contracted partition)")
+    ap.add_argument("--mode", choices=("auto", "consumer", "gather"), default="auto",
+                    help="slice shard: 'consumer' = sharded first Linear layer + reduce-scatter (auto picks it), 'gather' = all-gather of the embedding")
+    ap.add_argument("--chunks", type=int, default=0, help="node-range chunks of the multi-GPU pipeline (0 = by size)")
+    ap.add_argument("--output", choices=("replicated", "sharded"), default="replicated",
+                    help="consumer form: 'sharded' stops after the reduce-scatter (every rank keeps its finished rows)")
     return ap.parse_args()
 
 
@@ -131,22 +141,26 @@ def dominant_kernel_roofline(conv, x, ei, n, e_coalesced, reps, dev):
         kernel, kms = "k_embed_reg_unit", ms["embed_reg_unit"]
         alg_bytes = gather_bytes + 4.0 * rows_reg * (S + 1)       # + embedding written once
     secs = kms * 1e-3
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     if os.path.isfile(tpath):
         try:
-            traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(kernel + "_hbm_bytes_per_launch")
+            # NOT measured in this run: PMC passes are separate rocprofv3 runs (tools/refresh_profiles.sh); say where from
+            traffic_source = dict(tj.get("source", {}), file="profiles/pmc_traffic_latest.json")
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / secs / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "unit": "GB/s", "frac": alg_bytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kms,
             "bytes_per_edge_slice": alg_bytes / (float(e_coalesced) * S)}
     return roof, ms
 
 
-def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
-    """N > 1: the dominant kernel of a rank is k_embed_reg_unit on its own block of slices (unfused kernels + all-gather)."""
+def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world, consumer):
+    """N > 1: the dominant kernel of a rank over its own block of slices -- k_conv_fused_unit (sharded-consumer form:
+    gather of the block + the n x H partial sums written) or k_embed_reg_unit (gather form: block of the embedding written)."""
     from fsw_gnn_amd import _lib
     from fsw_gnn_amd.dist import slice_partition
     L = _lib.lib()
@@ -155,23 +169,59 @@ def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
     Sl = kb - ka
     stream = torch.cuda.current_stream(dev).cuda_stream
     graph = conv.build_graph(ei, n)
-    st = graph.stats()
-    ldp = (Sl + 63) // 64 * 64
-    Xp = torch.empty((n, ldp), dtype=torch.float32, device=dev)
-    V, fr = emb.projVecs.detach()[ka:kb], emb.freqs.detach()[ka:kb]
-    table = torch.empty((int(L.fsw_unit_table_rows(32)), ldp), dtype=torch.float32, device=dev)
-    out = torch.empty((n, 1 + Sl), dtype=torch.float32, device=dev)
-    _lib.check(L.fsw_project_f32(x.data_ptr(), n, D_FEAT, D_FEAT, V.data_ptr(), Sl, D_FEAT, Xp.data_ptr(), ldp, None, 0, None, stream), "project")
-    _lib.check(L.fsw_unit_coeff_table(fr.data_ptr(), Sl, 32, table.data_ptr(), ldp, stream), "table")
-    a = emb.make_args(graph, st, Xp, ldp, fr, Sl, table, out.data_ptr(), out.stride(0), None, 1.0, 1)
-    a.num_zero_rows = 0
-    kms = timed_ms(lambda: _lib.check(L.fsw_embed_f32(ctypes.byref(a), stream), "embed"), reps, dev)
+    prepared = emb.prepare(x, graph, slice_range=(ka, kb))
+    st = prepared["stats"]
+    fr = emb.freqs.detach()[ka:kb]
     edges = int(graph.rowptr[-1])
-    alg_bytes = 4.0 * edges * Sl + 4.0 * edges + 8.0 * n + 4.0 * st[_lib.STAT_NUM_REG] * (Sl + 1)
-    return {"bound": "hbm", "kernel": "k_embed_reg_unit (rank 0, %d of %d slices)" % (Sl, emb.nSlices),
+    H = conv.mlp[0].out_features
+    if consumer:
+        hm = 1 if rank == 0 else 0
+        wq, _ = conv._fused_weight(col0=0 if rank == 0 else 1 + ka, K=hm + Sl, want_w2=False)
+        y = torch.empty((n, H), dtype=torch.float32, device=dev)
+        a = emb.make_args(graph, st, prepared["Xp"], prepared["ldp"], fr, Sl, prepared["table"], None, 0, None, 1.0, hm, slice_offset=ka)
+        kms = timed_ms(lambda: _lib.check(L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0.0,
+                                                               y.data_ptr(), y.stride(0), stream), "fused"), reps, dev)
+        alg_bytes = 4.0 * edges * Sl + 4.0 * edges + 8.0 * n + 4.0 * n * H
+        kernel = "k_conv_fused_unit"
+    else:
+        out = torch.empty((n, 1 + Sl), dtype=torch.float32, device=dev)
+        a = emb.make_args(graph, st, prepared["Xp"], prepared["ldp"], fr, Sl, prepared["table"], out.data_ptr(), out.stride(0), None, 1.0, 1,
+                          slice_offset=ka)
+        a.num_zero_rows = 0
+        kms = timed_ms(lambda: _lib.check(L.fsw_embed_f32(ctypes.byref(a), stream), "embed"), reps, dev)
+        alg_bytes = 4.0 * edges * Sl + 4.0 * edges + 8.0 * n + 4.0 * st[_lib.STAT_NUM_REG] * (Sl + 1)
+        kernel = "k_embed_reg_unit"
+    return {"bound": "hbm", "kernel": "%s (rank 0, %d of %d slices)" % (kernel, Sl, emb.nSlices),
             "achieved": alg_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
             "ms_per_launch": kms}
+
+
+def collectives_alone(stats, n, H, width, world, reps, dev):
+    """The collectives of one step on same-size dummy buffers, nothing else on the GPU: milliseconds and the bus rate
+    (bytes a rank receives per second).  Un-overlapped: the step hides part of it under the kernels."""
+    if not stats:
+        return None
+    if stats.get("mode") == "consumer":
+        rows = -(-n // world) * world
+        P = torch.zeros((rows, H), dtype=torch.float32, device=dev)
+        R = torch.empty((rows // world, H), dtype=torch.float32, device=dev)
+
+        def fn():
+            dist.reduce_scatter_tensor(R, P)
+            if "all_gather" in stats.get("collective", ""):
+                dist.all_gather_into_tensor(P, R)
+    else:
+        loc = torch.zeros((n, width), dtype=torch.float32, device=dev)
+        flat = torch.empty((world * n, width), dtype=torch.float32, device=dev)
+
+        def fn():
+            dist.all_gather_into_tensor(flat, loc)
+    ms = timed_ms(fn, reps, dev)
+    t = torch.tensor([ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t)
+    return {"collective_ms": ms, "collective_GBps_per_rank": stats["bytes_received_per_rank"] / (ms * 1e-3) / 1e9}
 
 
 def node_sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
@@ -215,9 +265,24 @@ def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     t0 = time.time()
     C.embed(xh, rowptr, col, None, V, fr, s0=0, s1=nslices, nthreads=threads)
     secs = time.time() - t0
-    return {"value": float(eih.shape[1]) * nslices / secs, "unit": "edges*slices/sec", "cores": threads, "kind": "port",
-            "sample": "slices 0..%d of %d, all %d rows / %d edges, embedding core only (projection + sort + cumsum + readout), "
-                      "oracle/fsw_oracle.c with OpenMP, %.1f s" % (nslices - 1, V.shape[0], n, eih.shape[1], secs)}
+    res = {"value": float(eih.shape[1]) * nslices / secs, "unit": "edges*slices/sec", "cores": threads, "kind": "port",
+           "sample": "slices 0..%d of %d, all %d rows / %d edges, embedding core only (projection + sort + cumsum + readout), "
+                     "oracle/fsw_oracle.c with OpenMP, %.1f s" % (nslices - 1, V.shape[0], n, eih.shape[1], secs)}
+    # the reference's own CPU path (fsw_embedding.py, CUDA library disabled) cannot travel to this box; its figure was
+    # measured once in the build container by oracle/make_goldens.py and is quoted here with its provenance
+    try:
+        rt = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_timings.json")))
+        secs_ref = float(rt["er1m_fp64_forward_seconds"])
+        res["reference_cpu"] = {
+            "value": float(rt["er1m_edges_coalesced"]) * rt["er1m_slices"] / secs_ref, "unit": "edges*slices/sec",
+            "cores": rt["cpu_threads"], "seconds": secs_ref,
+            "provenance": "the unmodified reference FSW_embedding.forward (device='cpu', load_custom_cuda_lib=False, float64, "
+                          "serialize_num_slices=%d) on BASELINE config 3, build container (8 cores, torch %s), "
+                          "tests/golden/ref_timings.json written by oracle/make_goldens.py -- NOT measured on this box"
+                          % (rt["er1m_serialize_num_slices"], rt["torch"])}
+    except Exception:
+        pass
+    return res
 
 
 def main():
@@ -247,11 +312,13 @@ def main():
     conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=EMBED_DIM, device=dev)
     if args.no_fuse:
         conv.fuse_linear = False
+    sp_stats = {}
     if world > 1:
         if args.shard == "nodes" and not args.no_fuse:
             conv.enable_node_parallel(None)
         else:
-            conv.enable_slice_parallel(None)
+            conv.enable_slice_parallel(None, mode="gather" if args.no_fuse else args.mode, chunks=args.chunks or None,
+                                       output=args.output, stats=sp_stats)
     S = conv.fsw_embed.nSlices
     keys = ei[1] * n + ei[0]
     e_coalesced = int(torch.unique(keys).numel())          # E' of SURVEY 8(d): edges after the reference's coalesce()
@@ -279,7 +346,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
-    assert torch.isfinite(y).all()
+    assert torch.isfinite(y[0] if isinstance(y, tuple) else y).all()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = float(e_coalesced) * S * args.steps / elapsed
@@ -293,7 +360,8 @@ def main():
                    "nodes": n, "edges": E, "edges_coalesced": e_coalesced, "slices": S, "features": D_FEAT,
                    "parallelism": ("single GPU" if world == 1 else
                                    "recipient-row shard x%d, all-gather of the output rows" % world if getattr(conv, "_node_parallel", False)
-                                   else "slice-shard x%d, all-gather of the embedding" % world)},
+                                   else "slice-axis shard x%d (%d slices per rank), %s form: %s" % (
+                                       world, S // world, sp_stats.get("mode", "?"), sp_stats.get("collective", "?")))},
         # fraction of the 8 TB/s roofline for the WHOLE forward at SURVEY 8(d)'s 5.13 B per edge*slice (incl. CSR build)
         "path_roofline_frac": value * 5.13 / (HBM_PEAK_GBS * 1e9),
     }
@@ -304,8 +372,28 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
     if world > 1:
-        fn = node_sharded_kernel_roofline if getattr(conv, "_node_parallel", False) else sharded_kernel_roofline
-        roof = fn(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)   # every rank runs it
+        if getattr(conv, "_node_parallel", False):
+            roof = node_sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)
+        else:
+            from fsw_gnn_amd import dist as D
+            consumer = sp_stats.get("mode") == "consumer"
+            roof = sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world, consumer)   # every rank runs it
+            # the same step with every collective replaced by a local copy = this rank's compute
+            D.COLLECTIVES_ENABLED = False
+            cms = timed_ms(step, max(3, args.kernel_reps // 4), dev)
+            D.COLLECTIVES_ENABLED = True
+            t = torch.tensor([cms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            result["compute_ms"] = float(t)
+            H = conv.mlp[0].out_features
+            width = 1 + max(b - a for a, b in D.slice_partition(S, world))
+            coll = collectives_alone(sp_stats, n, H, width, world, max(3, args.kernel_reps // 4), dev)
+            if coll:
+                result.update(coll)
+            result["bytes_sent_per_rank"] = sp_stats.get("bytes_sent_per_rank")
+            result["bytes_received_per_rank"] = sp_stats.get("bytes_received_per_rank")
+            result["slice_parallel"] = {k: sp_stats.get(k) for k in ("mode", "collective")}
+            result["slice_parallel"]["output"] = args.output
         if rank == 0:
             result["roofline"] = roof
     if rank == 0:

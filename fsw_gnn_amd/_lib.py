@@ -11,14 +11,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FSW_HIP_LIBRARY: another build of the same library (kernel tuning experiments, tools/exp_variants.sh)
 LIB_PATH = os.environ.get("FSW_HIP_LIBRARY") or os.path.join(_HERE, "libfsw_hip.so")
 
-FSW_ABI_VERSION = 2
+FSW_ABI_VERSION = 3
 REG_MAX_DEG = 32
 LDS_MAX_DEG = 2048
 MID_SIZES = (40, 48, 64, 80, 96, 128, 160, 192, 256)   # FSW_MID_SIZES: padded register-path networks above REG_MAX_DEG
 NUM_LDS_BINS = 3                                          # FSW_NUM_LDS_BINS: degrees <= 512, 1024, 2048
 NUM_BINS = REG_MAX_DEG + 1 + len(MID_SIZES) + NUM_LDS_BINS + 1
 NUM_STATS = 8
-STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL, STAT_NNZ = 0, 1, 2, 3, 4, 5, 6
+STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL, STAT_NNZ, STAT_USER = 0, 1, 2, 3, 4, 5, 6, 7
+BIN_BLOCK_ROWS, MAX_ROW_CHUNKS = 2048, 256
 FLAG_INDEX_RANGE, FLAG_W_NONFINITE, FLAG_W_NEGATIVE, FLAG_X_NONFINITE = 1, 2, 4, 8
 
 c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -46,13 +47,15 @@ _SIGNATURES = {
     "fsw_graph_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "fsw_graph_build_coalesced": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_project_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_unit_table_rows": (c_sz, [ctypes.c_int]),
     "fsw_unit_coeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_scratch_bytes": (c_sz, [c_i64]),
     "fsw_embed_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp]),
     "fsw_conv_fused_lds_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "fsw_packed_linear_floats": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "fsw_pack_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_project_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64,
                                               c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, c_vp, c_i64,

@@ -23,6 +23,7 @@
 // HBM traffic per forward drops by ~3.6 GB at BASELINE config 3 (no E write, no E/x re-read, no concat, no
 // activation pass).
 #include <stdlib.h>
+#include <algorithm>
 #include "fsw_common.h"
 #include "sortnet.h"
 #include "row_pipeline.h"
@@ -184,12 +185,20 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
       H[r * a.ldh] = a.out_scale * (mass_encode_f((float)D, a.mass_fn) * a.mass_scale + (a.bias ? a.bias[0] : 0.f));
   }
   // phase 1: embedding rows
+  // a wave = one 64-slice chunk of a group of rows.  Four or more chunks: every wave walks all 32 rows of its chunks.
+  // Narrow slice blocks (one rank's share of a slice-sharded layer, dist.py): the rows are split into 4 / nchunks
+  // groups so that all four waves still gather.
   const int nchunks = (a.S + kWave - 1) / kWave;
-  for (int chunk = wv; chunk < nchunks; chunk += 4) {
+  const int ngroups = nchunks >= 3 ? 1 : 4 / nchunks;
+  const int grows = kFusedRows / ngroups;
+  for (int item = wv; item < nchunks * ngroups; item += 4) {
+    const int chunk = item / ngroups, r0 = (item - chunk * ngroups) * grows;
+    const int gn = min(nrows - r0, grows);
+    if (gn <= 0) continue;
     switch (D) {
 #define X(d)                                                  \
   case d:                                                     \
-    if constexpr (d >= DLO && d <= DHI) fused_embed_rows<d>(a, p, nrows, H, chunk); \
+    if constexpr (d >= DLO && d <= DHI) fused_embed_rows<d>(a, p + r0, gn, H + r0 * a.ldh, chunk); \
     break;
       FSW_CASES_0_32(X)
 #undef X
@@ -270,9 +279,49 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
   }
 }
 
+// W = [W1 | W2] of the first Linear layer -> the packed operand of slab_mma (layout: include/fsw_hip.h) and a
+// contiguous copy of W2.  One launch per forward instead of a host-side cache that an in-place weight edit could outdate.
+__global__ void __launch_bounds__(256) k_pack_linear(const float* __restrict__ W, int64_t ldw_in, int Hout, int col0, int K,
+                                                     float* __restrict__ Wq, int64_t ldwq, int64_t ngroups,
+                                                     const float* __restrict__ W2, int d2, float* __restrict__ W2out, int64_t ldw2out) {
+  const int64_t nq = ngroups * ldwq * 8;
+  const int64_t total = nq + (W2out ? (int64_t)Hout * d2 : 0);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx < nq) {
+      const int e = (int)(idx & 7), h = e >> 2, i = e & 3;
+      const int64_t gj = idx >> 3;
+      const int64_t g = gj / ldwq, j = gj - g * ldwq;
+      const int64_t k = 8 * g + 2 * i + h;
+      Wq[idx] = (j < Hout && k < K) ? W[j * ldw_in + col0 + k] : 0.f;
+    } else {
+      const int64_t t = idx - nq;
+      const int64_t j = t / d2, c = t - j * d2;
+      W2out[j * ldw2out + c] = W2[j * ldw_in + c];
+    }
+  }
+}
+
 }  // namespace fsw
 
 using namespace fsw;
+
+extern "C" size_t fsw_packed_linear_floats(int K, int Hout) {
+  return (size_t)(((K + 7) / 8) + 16) * (size_t)(((Hout + 31) / 32) * 32) * 8;
+}
+
+extern "C" int fsw_pack_linear_f32(const float* W, int64_t ldw_in, int Hout, int col0, int K, float* Wq, const float* W2, int d2,
+                                   float* W2out, int64_t ldw2out, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  FSW_REQUIRE(W && Wq && Hout >= 1 && K >= 1 && col0 >= 0 && ldw_in >= col0 + K, "fsw_pack_linear_f32: bad arguments");
+  FSW_REQUIRE(((uintptr_t)Wq & 15) == 0, "fsw_pack_linear_f32: Wq must be 16-byte aligned");
+  FSW_REQUIRE(!W2out || (W2 && d2 >= 1 && ldw2out >= d2), "fsw_pack_linear_f32: bad W2 block");
+  const int64_t ldwq = ((Hout + 31) / 32) * 32, ngroups = (K + 7) / 8 + 16;
+  const int64_t total = ngroups * ldwq * 8 + (W2out ? (int64_t)Hout * d2 : 0);
+  k_pack_linear<<<(unsigned)std::min<int64_t>(ceil_div(total, 256), 2048), 256, 0, stream>>>(W, ldw_in, Hout, col0, K, Wq, ldwq, ngroups, W2,
+                                                                                            d2, W2out, ldw2out);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
   const int Kp = (has_mass + S + 7) & ~7;

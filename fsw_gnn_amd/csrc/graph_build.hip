@@ -323,17 +323,28 @@ __device__ __forceinline__ unsigned long long match_bin(int bin, bool valid) {
   return peers;
 }
 
-__global__ void __launch_bounds__(256) k_bin_count(const int32_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ bin_count,
-                                                   int32_t* __restrict__ stats) {
+// Row chunks: with chunk_rows > 0 the rows are binned separately inside every chunk of chunk_rows consecutive rows
+// (a multiple of kBinRowsPerBlock, so a workgroup never straddles two chunks): perm lists chunk 0's rows by degree bin, then
+// chunk 1's, ..., and bin_start holds one row of FSW_NUM_BINS + 1 offsets per chunk.  A kernel handed chunk c's row of
+// bin_start visits exactly the recipients [c * chunk_rows, (c + 1) * chunk_rows) -- that is how the multi-GPU path
+// overlaps the collective of one node range with the kernels of the next (dist.py).
+constexpr int kBinItems = 8;
+constexpr int kBinRowsPerBlock = 256 * kBinItems;
+constexpr int kMaxRowChunks = 256;
+static_assert(kBinRowsPerBlock == FSW_BIN_BLOCK_ROWS, "include/fsw_hip.h documents the chunk granularity");
+
+__global__ void __launch_bounds__(256) k_bin_count(const int32_t* __restrict__ rowptr, int64_t n, int64_t chunk_rows,
+                                                   int32_t* __restrict__ bin_count, int32_t* __restrict__ stats) {
   __shared__ int lbin[FSW_NUM_BINS];
   __shared__ int lmax;
   if (threadIdx.x < FSW_NUM_BINS) lbin[threadIdx.x] = 0;
   if (threadIdx.x == 0) lmax = 0;
   __syncthreads();
   int mx = 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t r0 = (int64_t)blockIdx.x * blockDim.x; r0 < n; r0 += stride) {   // uniform trip count per workgroup
-    const int64_t r = r0 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kBinRowsPerBlock + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < kBinItems; ++i) {
+    const int64_t r = r0 + (int64_t)i * 256;
     const bool valid = r < n;
     const int deg = valid ? rowptr[r + 1] - rowptr[r] : 0;
     const int bin = degree_bin(deg);
@@ -345,37 +356,54 @@ __global__ void __launch_bounds__(256) k_bin_count(const int32_t* __restrict__ r
   for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
   if (lane_id() == 0) atomicMax(&lmax, mx);
   __syncthreads();
-  if (threadIdx.x < FSW_NUM_BINS && lbin[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], lbin[threadIdx.x]);
+  const int64_t chunk = ((int64_t)blockIdx.x * kBinRowsPerBlock) / chunk_rows;
+  if (threadIdx.x < FSW_NUM_BINS && lbin[threadIdx.x]) atomicAdd(&bin_count[chunk * FSW_NUM_BINS + threadIdx.x], lbin[threadIdx.x]);
   if (threadIdx.x == 0 && lmax) atomicMax(&stats[FSW_STAT_MAX_DEGREE], lmax);
 }
 
-__global__ void k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_start,
-                              int32_t* __restrict__ bin_cursor, int32_t* __restrict__ stats) {
-  if (threadIdx.x == 0) {
-    int acc = 0, reg = 0;
-    for (int b = 0; b < FSW_NUM_BINS; ++b) {
-      bin_start[b] = acc;
-      bin_cursor[b] = acc;
-      if (b >= 1 && b <= FSW_REG_MAX_DEG) reg += bin_count[b];
-      acc += bin_count[b];
+__global__ void __launch_bounds__(kMaxRowChunks) k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_start,
+                                                               int32_t* __restrict__ bin_cursor, int32_t* __restrict__ stats,
+                                                               int num_chunks) {
+  __shared__ int ctot[kMaxRowChunks];
+  const int c = threadIdx.x;
+  int tot = 0;
+  if (c < num_chunks)
+    for (int b = 0; b < FSW_NUM_BINS; ++b) tot += bin_count[c * FSW_NUM_BINS + b];
+  ctot[c] = tot;
+  __syncthreads();
+  if (c == 0) {
+    int acc = 0;
+    for (int i = 0; i < num_chunks; ++i) {
+      const int t = ctot[i];
+      ctot[i] = acc;
+      acc += t;
     }
-    bin_start[FSW_NUM_BINS] = acc;
-    stats[FSW_STAT_NUM_ZERO_DEG] = bin_count[0];
-    stats[FSW_STAT_NUM_REG] = reg;
-    int mid = 0;
-    for (int b = FSW_BIN_MID0; b < FSW_BIN_GLOBAL; ++b) mid += bin_count[b];
-    stats[FSW_STAT_NUM_LDS] = mid;
-    stats[FSW_STAT_NUM_GLOBAL] = bin_count[FSW_BIN_GLOBAL];
+  }
+  __syncthreads();
+  if (c < num_chunks) {
+    int acc = ctot[c], reg = 0, mid = 0;
+    const int32_t* cnt = bin_count + c * FSW_NUM_BINS;
+    int32_t* bs = bin_start + c * (FSW_NUM_BINS + 1);
+    for (int b = 0; b < FSW_NUM_BINS; ++b) {
+      bs[b] = acc;
+      bin_cursor[c * FSW_NUM_BINS + b] = acc;
+      if (b >= 1 && b <= FSW_REG_MAX_DEG) reg += cnt[b];
+      if (b >= FSW_BIN_MID0 && b < FSW_BIN_GLOBAL) mid += cnt[b];
+      acc += cnt[b];
+    }
+    bs[FSW_NUM_BINS] = acc;
+    if (cnt[0]) atomicAdd(&stats[FSW_STAT_NUM_ZERO_DEG], cnt[0]);
+    if (reg) atomicAdd(&stats[FSW_STAT_NUM_REG], reg);
+    if (mid) atomicAdd(&stats[FSW_STAT_NUM_LDS], mid);
+    if (cnt[FSW_BIN_GLOBAL]) atomicAdd(&stats[FSW_STAT_NUM_GLOBAL], cnt[FSW_BIN_GLOBAL]);
   }
 }
 
 // A workgroup places kBinRowsPerBlock consecutive rows: per-bin counts accumulate in LDS over the rounds (a lane's rank
 // is the running count before its round + its rank among its wave peers), then ONE global atomic per bin claims the
-// workgroup's range -- the 35 cursors are shared by every workgroup, so same-address atomics are the cost to keep low.
-constexpr int kBinItems = 8;
-constexpr int kBinRowsPerBlock = 256 * kBinItems;
-
-__global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ rowptr, int64_t n,
+// workgroup's range -- the cursors of a chunk are shared by all its workgroups, so same-address atomics are the cost to
+// keep low.
+__global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ rowptr, int64_t n, int64_t chunk_rows,
                                                   int32_t* __restrict__ bin_cursor, int32_t* __restrict__ perm,
                                                   int32_t* __restrict__ invperm) {
   __shared__ int lcount[FSW_NUM_BINS];
@@ -396,7 +424,9 @@ __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ ro
     rank[i] = __shfl(prev, leader) + __popcll(peers & ((1ull << lane_id()) - 1ull));
   }
   __syncthreads();
-  if (threadIdx.x < FSW_NUM_BINS && lcount[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], lcount[threadIdx.x]);
+  const int64_t chunk = ((int64_t)blockIdx.x * kBinRowsPerBlock) / chunk_rows;
+  if (threadIdx.x < FSW_NUM_BINS && lcount[threadIdx.x])
+    lbase[threadIdx.x] = atomicAdd(&bin_cursor[chunk * FSW_NUM_BINS + threadIdx.x], lcount[threadIdx.x]);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kBinItems; ++i) {
@@ -410,6 +440,8 @@ __global__ void __launch_bounds__(256) k_bin_rows(const int32_t* __restrict__ ro
 }
 
 // ---- workspace ---------------------------------------------------------------------------------------------------
+constexpr size_t kBinTableBytes = sizeof(int32_t) * kMaxRowChunks * FSW_NUM_BINS;
+
 struct GraphWs {
   uint32_t* keys[2];
   void* vals[2];
@@ -436,8 +468,8 @@ static GraphWs carve(void* ws, int64_t num_edges) {
   g.vals[1] = take(8 * E);
   g.counts = reinterpret_cast<int32_t*>(take(4 * (size_t)kRsMaxDigits * ntiles));
   g.block_sums = reinterpret_cast<int32_t*>(take(4 * (size_t)(ceil_div((int64_t)(kRsMaxDigits * ntiles), kScanTile) + 1)));
-  g.bin_count = reinterpret_cast<int32_t*>(take(512));
-  g.bin_cursor = reinterpret_cast<int32_t*>(take(512));
+  g.bin_count = reinterpret_cast<int32_t*>(take(kBinTableBytes));
+  g.bin_cursor = reinterpret_cast<int32_t*>(take(kBinTableBytes));
   g.total = (size_t)(p - reinterpret_cast<char*>(ws));
   return g;
 }
@@ -559,15 +591,25 @@ __global__ void __launch_bounds__(256) k_rowptr_from_keys(const uint32_t* __rest
   }
 }
 
-static int finish_bins(int32_t* rowptr, int64_t num_rows, int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats,
-                       GraphWs& g, hipStream_t stream) {
-  const int row_blocks = (int)std::min<int64_t>(ceil_div(num_rows, 256), 512);   // few workgroups: each ends in 35 same-address atomics
-  k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, g.bin_count, stats);
+static int finish_bins(int32_t* rowptr, int64_t num_rows, int64_t chunk_rows, int32_t* perm, int32_t* invperm, int32_t* bin_start,
+                       int32_t* stats, GraphWs& g, hipStream_t stream) {
+  if (chunk_rows <= 0) chunk_rows = ceil_div(num_rows, kBinRowsPerBlock) * kBinRowsPerBlock;   // one chunk
+  const int num_chunks = (int)ceil_div(num_rows, chunk_rows);
+  const int row_blocks = (int)ceil_div(num_rows, kBinRowsPerBlock);
+  k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, chunk_rows, g.bin_count, stats);
   FSW_LAUNCH_CHECK();
-  k_bin_offsets<<<1, 64, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats);
+  k_bin_offsets<<<1, kMaxRowChunks, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats, num_chunks);
   FSW_LAUNCH_CHECK();
-  k_bin_rows<<<(int)ceil_div(num_rows, kBinRowsPerBlock), 256, 0, stream>>>(rowptr, num_rows, g.bin_cursor, perm, invperm);
+  k_bin_rows<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, chunk_rows, g.bin_cursor, perm, invperm);
   FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+static int check_chunks(int64_t num_rows, int64_t chunk_rows) {
+  FSW_REQUIRE(chunk_rows >= 0 && chunk_rows % kBinRowsPerBlock == 0,
+              "fsw_graph_build: chunk_rows must be 0 or a positive multiple of %d", kBinRowsPerBlock);
+  FSW_REQUIRE(chunk_rows == 0 || ceil_div(num_rows, chunk_rows) <= kMaxRowChunks, "fsw_graph_build: more than %d row chunks",
+              kMaxRowChunks);
   return 0;
 }
 
@@ -582,9 +624,9 @@ extern "C" size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges)
 }
 
 extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
-                               int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* perm,
-                               int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace, size_t workspace_bytes,
-                               fsw_stream_t stream_) {
+                               int64_t num_rows, int64_t num_cols, int64_t chunk_rows, int32_t* rowptr, int32_t* col, float* w,
+                               int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
+                               size_t workspace_bytes, fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) - 1 && num_cols >= 1 && num_cols < (1ll << 31) && num_edges >= 0 &&
                   num_edges < (1ll << 31) - kRsTile,
@@ -595,9 +637,10 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
   FSW_REQUIRE(rowptr && perm && bin_start && stats && (num_edges == 0 || (col && recipients && senders)),
               "fsw_graph_build: null pointer");
   FSW_REQUIRE(!edge_w || w, "fsw_graph_build: edge_w given but w is null");
+  if (int rc = check_chunks(num_rows, chunk_rows)) return rc;
   GraphWs g = carve(workspace, num_edges);
 
-  FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, 512, stream));
+  FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, kBinTableBytes, stream));
   FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
   if (num_edges == 0) {
     FSW_CHECK_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
@@ -606,7 +649,7 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
                     : sort_and_finish<uint32_t>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream);
     if (rc) return rc;
   }
-  return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
+  return finish_bins(rowptr, num_rows, chunk_rows, perm, invperm, bin_start, stats, g, stream);
 }
 
 extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_t* senders, const float* edge_w,
@@ -624,11 +667,11 @@ extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_
               "fsw_graph_build_coalesced: null pointer");
   FSW_REQUIRE(d_edge >= 0 && (d_edge == 0 || (edge_feat && ef)), "fsw_graph_build_coalesced: edge features need edge_feat and ef");
   GraphWs g = carve(workspace, num_edges);
-  FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, 512, stream));
+  FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, kBinTableBytes, stream));
   FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
   if (num_edges == 0) {
     FSW_CHECK_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
-    return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
+    return finish_bins(rowptr, num_rows, 0, perm, invperm, bin_start, stats, g, stream);
   }
   if (slot_of_edge) FSW_CHECK_HIP(hipMemsetAsync(slot_of_edge, 0xff, sizeof(int32_t) * (size_t)num_edges, stream));
   const int edge_blocks = (int)std::min<int64_t>(ceil_div(num_edges, 256), 256 * 16);
@@ -661,5 +704,5 @@ extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_
   FSW_LAUNCH_CHECK();
   k_rowptr_from_keys<<<edge_blocks, 256, 0, stream>>>(keyc, nnz_dev, num_rows, rowptr);
   FSW_LAUNCH_CHECK();
-  return finish_bins(rowptr, num_rows, perm, invperm, bin_start, stats, g, stream);
+  return finish_bins(rowptr, num_rows, 0, perm, invperm, bin_start, stats, g, stream);
 }

@@ -149,7 +149,7 @@ class FSW_conv(_Base):
         self.to(device=device, dtype=dtype)
 
     # ------------------------------------------------------------------------------------------------
-    def build_graph(self, edge_index, num_vertices, edge_features=None):
+    def build_graph(self, edge_index, num_vertices, edge_features=None, chunk_rows=0):
         """edge_index [2, E] int64 (row 0 = sender, row 1 = recipient) -> CSRGraph.
 
         With edge features (edgefeat_dim > 0, fsw_conv.py:419-439) the adjacency is coalesced like the reference's:
@@ -159,6 +159,7 @@ class FSW_conv(_Base):
         (fsw_conv.py:390-395) append n weighted edges; 'gcn' weighting (fsw_conv.py:406-409) divides every
         edge by sqrt(deg_recipient) * sqrt(deg_sender) with deg = weighted in-degree.  Parallel edges stay
         separate elements (see DESIGN.md "duplicates"), which gives the same sums as the reference's coalesce.
+        chunk_rows > 0: degree bins per chunk of consecutive rows (graph.py; the multi-GPU pipeline).
         """
         if edge_features is not None:
             src, dst = edge_index[0], edge_index[1]
@@ -179,18 +180,21 @@ class FSW_conv(_Base):
             return build_csr_coalesced(dst, src, w, ef.contiguous(), num_vertices, num_vertices, want_slots=True)
         if self.cache_graph:
             # optional CSR reuse across calls / layers.  Off by default: the reference rebuilds its
-            # adjacency on every forward (fsw_conv.py:352) and bench.py times the rebuild.
-            key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_vertices),
-                   float(self.self_loop_weight), self.edge_weighting)
+            # adjacency on every forward (fsw_conv.py:352) and bench.py times the rebuild.  The cache entry keeps the
+            # edge_index tensor itself alive, so its address cannot be handed to another batch by the caching allocator;
+            # an in-place edit bumps _version.  The flags earlier inputs left behind are cleared on a hit.
+            key = (edge_index._version, tuple(edge_index.shape), int(num_vertices), float(self.self_loop_weight),
+                   self.edge_weighting, int(chunk_rows))
             hit = getattr(self, '_graph_cache', None)
-            if hit is not None and hit[0] == key:
-                return hit[1]
+            if hit is not None and hit[0] is edge_index and hit[1] == key:
+                hit[2].clear_input_flags()
+                return hit[2]
             self.cache_graph = False
             try:
-                graph = self.build_graph(edge_index, num_vertices)
+                graph = self.build_graph(edge_index, num_vertices, chunk_rows=chunk_rows)
             finally:
                 self.cache_graph = True
-            self._graph_cache = (key, graph)
+            self._graph_cache = (edge_index, key, graph)
             return graph
         src, dst = edge_index[0], edge_index[1]
         w = None
@@ -206,7 +210,7 @@ class FSW_conv(_Base):
             deg = torch.zeros(num_vertices, device=src.device, dtype=torch.float32).scatter_add_(0, dst, w)
             ds = torch.sqrt(deg)
             w = w / ds[dst] / ds[src]
-        return build_csr(dst, src, w, num_vertices, num_vertices, want_invperm=self._fusable())
+        return build_csr(dst, src, w, num_vertices, num_vertices, want_invperm=self._fusable(), chunk_rows=chunk_rows)
 
     def forward(self, vertex_features, edge_index, edge_features=None):
         """vertex_features [n, in_channels], edge_index [2, E] long -> [n, out_channels] (fsw_conv.py:331-369)."""
@@ -230,28 +234,28 @@ class FSW_conv(_Base):
         needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters())
                                                   or (edge_features is not None and edge_features.requires_grad))
         n = vertex_features.size(0)
+        if n == 0:
+            return torch.zeros((0, self.out_channels), dtype=vertex_features.dtype, device=vertex_features.device)
         x = vertex_features.contiguous()
         if getattr(self, '_node_parallel', False):
             if needs_grad:
                 raise NotImplementedError("fsw_gnn_amd: node-parallel training is not implemented")
             return self._forward_node_parallel(x, edge_index)
+        sp = getattr(self, '_slice_parallel', None)
+        if sp is not None:
+            return self._forward_slice_parallel(sp, x, vertex_features, edge_index, edge_features, needs_grad)
         graph = self.build_graph(edge_index, n, edge_features if self.edgefeat_dim > 0 else None)
         E = self.embed_dim
         scale = float(self.message_weight_vs_self) if self.concat_self else 1.0      # fsw_conv.py:357-358
-        sharded = getattr(self, '_slice_parallel', False)
 
         if needs_grad:
             # training path: differentiable embedding (HIP forward + backward kernels), the tail through torch autograd
-            if sharded:
-                raise NotImplementedError("fsw_gnn_amd: slice-parallel training is not implemented")
             ef_in = edge_features.reshape(edge_index.shape[1], -1) if self.edgefeat_dim > 0 else None
             emb = emb_mod.embed_autograd(x, graph, edge_feat=ef_in)
-            h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
-            out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
-            return self.bn_final(out) if self.bn_final is not None else out
+            return self._tail(emb, vertex_features)
 
         prepared = None
-        if self._fusable() and not sharded:
+        if self._fusable():
             # fast path: the projection GEMM also produces x . W2^T + b, then ONE kernel does the neighbourhood
             # embedding and E . W1^T (+ activation); the embedding never reaches HBM (csrc/conv_fused.hip)
             lin = self.mlp[0]
@@ -270,24 +274,88 @@ class FSW_conv(_Base):
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
         xc = buf[:, E:] if self.concat_self else None   # right half of cat((emb, x))
-        if sharded:
-            from .dist import sharded_embed_into
-            sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=self._slice_parallel_group, x_copy=xc)
-        elif prepared is not None:                       # fusable configuration, but the graph has long rows
+        if prepared is not None:                       # fusable configuration, but the graph has long rows
             emb_mod.embed_into(x, graph, buf, out_scale=scale, prepared=prepared)
             if xc is not None:
                 xc.copy_(x)
         else:
             emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)   # X stored by the projection kernel
+        return self._tail_buffer(buf)
+
+    def _tail(self, emb, vertex_features):
+        """concat with the vertex features, MLP / dim_reduct, final BatchNorm through torch autograd (fsw_conv.py:357-369)."""
+        h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
+        out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
+        return self.bn_final(out) if self.bn_final is not None else out
+
+    def _tail_buffer(self, buf):
+        """The same tail on the concat buffer the kernels filled in place (inference)."""
         if self.mlp is not None:
             out = self.mlp(buf)
         elif self.concat_self:
             out = torch.matmul(buf, self.dim_reduct.transpose(0, 1))
         else:
             out = buf
-        if self.bn_final is not None:
-            out = self.bn_final(out)
-        return out
+        return self.bn_final(out) if self.bn_final is not None else out
+
+    def _forward_slice_parallel(self, sp, x, vertex_features, edge_index, edge_features, needs_grad):
+        """Slice-axis sharding over the ranks of sp['group'] (dist.py: gather / consumer / training forms)."""
+        import torch.distributed as dist
+        from . import dist as D
+        group = sp['group']
+        world = dist.get_world_size(group)
+        emb_mod = self.fsw_embed
+        n = x.shape[0]
+        E = self.embed_dim
+        scale = float(self.message_weight_vs_self) if self.concat_self else 1.0
+        has_ef = self.edgefeat_dim > 0
+        stats = sp.get('stats')
+        if stats is not None:
+            stats.clear()
+        if needs_grad:
+            graph = self.build_graph(edge_index, n, edge_features if has_ef else None)
+            ef_in = edge_features.reshape(edge_index.shape[1], -1) if has_ef else None
+            emb = D.sharded_embed_autograd(emb_mod, x, graph, out_scale=1.0, group=group, edge_feat=ef_in)
+            return self._tail(emb, vertex_features)
+        chunk_rows = 0
+        if world > 1 and not has_ef:
+            nch = sp['chunks'] if sp['chunks'] else D.default_chunks(n)
+            chunk_rows, _ = D.chunk_plan(n, world, nch)
+        graph = self.build_graph(edge_index, n, edge_features if has_ef else None, chunk_rows=chunk_rows)
+        rank = dist.get_rank(group)
+        parts = D.slice_partition(emb_mod.nSlices, world)
+        mode = sp['mode']
+        prepared = None
+        if world > 1 and mode in ('auto', 'consumer') and self._fusable() and parts[0][1] > parts[0][0]:
+            prepared = emb_mod.prepare(x, graph, slice_range=parts[rank])
+            st = prepared["stats"]
+            if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
+                res, next_module = D.consumer_forward(self, x, graph, prepared, scale, group, sp['output'], stats)
+                if stats is not None:
+                    stats["mode"] = "consumer"
+                if sp['output'] == 'sharded':
+                    R, row0 = res
+                    for m in self.mlp[next_module:]:
+                        R = m(R)
+                    return R, row0
+                y = res
+                for m in self.mlp[next_module:]:
+                    y = m(y)
+                return y
+            if mode == 'consumer':
+                raise NotImplementedError("fsw_gnn_amd: the sharded-consumer form needs unit weights and rows of at most %d neighbours"
+                                          % _lib.REG_MAX_DEG)
+        elif mode == 'consumer' and world > 1:
+            raise NotImplementedError("fsw_gnn_amd: the sharded-consumer form needs the fused configuration (csrc/conv_fused.hip)")
+        if sp['output'] == 'sharded':
+            raise NotImplementedError("fsw_gnn_amd: output='sharded' exists for the sharded-consumer form only")
+        width = E + self.in_channels if self.concat_self else E
+        buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
+        xc = buf[:, E:] if self.concat_self else None
+        D.sharded_embed_into(emb_mod, x, graph, buf, out_scale=scale, group=group, x_copy=xc, prepared=prepared, stats=stats)
+        if stats is not None:
+            stats["mode"] = "gather"
+        return self._tail_buffer(buf)
 
     # ------------------------------------------------------------------------------------------------
     fuse_linear = True   # class-level switch: set conv.fuse_linear = False to force the unfused kernels
@@ -304,22 +372,26 @@ class FSW_conv(_Base):
             return False
         return int(_lib.lib().fsw_conv_fused_lds_bytes(emb.nSlices, 1 if emb.encode_total_mass else 0)) <= 64 * 1024
 
-    def _fused_weight(self):
-        """(Wq, W2) of the first Linear layer W = [W1 | W2]: W1^T packed for 16-byte MFMA operand loads
-        (layout: include/fsw_hip.h, fsw_conv_fused_f32) and W2 contiguous; cached until the weight changes."""
+    def _fused_weight(self, col0=0, K=None, want_w2=True):
+        """(Wq, W2) of the first Linear layer W = [W1 | W2]: K columns of W1 from column col0 (default: all embed_dim
+        columns) packed for 16-byte MFMA operand loads (layout: include/fsw_hip.h, fsw_conv_fused_f32) and a contiguous
+        copy of W2.  Packed by ONE kernel launch on every call -- nothing is cached, so in-place edits of the weights
+        (EMA / SWA swaps, clipping, weight.data.copy_) are always seen."""
+        L = _lib.lib()
         lin = self.mlp[0]
-        key = (lin.weight.data_ptr(), lin.weight._version, tuple(lin.weight.shape))
-        cache = getattr(self, '_wt_cache', None)
-        if cache is None or cache[0] != key:
-            W = lin.weight.detach()
-            Hout, E = W.shape[0], self.embed_dim
-            Kp, ldw = (E + 7) // 8 * 8 + 16 * 8, (Hout + 31) // 32 * 32     # + 16 zero groups: the kernel prefetches ahead
-            wpad = torch.zeros((ldw, Kp), dtype=W.dtype, device=W.device)
-            wpad[:Hout, :E] = W[:, :E]
-            wq = wpad.view(ldw, Kp // 8, 4, 2).permute(1, 0, 3, 2).contiguous()     # [g][j][h][i] = W1[j][8g + 2i + h]
-            w2 = W[:, E:].contiguous() if self.concat_self else None
-            self._wt_cache = (key, wq, w2)
-        return self._wt_cache[1], self._wt_cache[2]
+        W = lin.weight.detach()
+        Hout, E = W.shape[0], self.embed_dim
+        K = E if K is None else K
+        ldwq = (Hout + 31) // 32 * 32
+        wq = torch.empty(int(L.fsw_packed_linear_floats(K, Hout)), dtype=W.dtype, device=W.device).view(-1, ldwq, 8)
+        w2 = None
+        if want_w2 and self.concat_self:
+            w2 = torch.empty((Hout, self.in_channels), dtype=W.dtype, device=W.device)
+        rc = L.fsw_pack_linear_f32(_lib.ptr(W), W.stride(0), Hout, col0, K, _lib.ptr(wq),
+                                   ctypes.c_void_p(W.data_ptr() + 4 * E) if w2 is not None else None, self.in_channels,
+                                   _lib.ptr(w2), self.in_channels, torch.cuda.current_stream(W.device).cuda_stream)
+        _lib.check(rc, "fsw_pack_linear_f32")
+        return wq, w2
 
     def _fused_linear(self, graph, prepared, scale, wq, yin, y):
         L = _lib.lib()
@@ -405,10 +477,19 @@ class FSW_conv(_Base):
             y = m(y)
         return self.bn_final(y) if self.bn_final is not None else y
 
-    def enable_slice_parallel(self, group=None, enabled=True):
-        """Shard the slice axis of the embedding over the ranks of `group` (dist.py); one all-gather per forward."""
-        self._slice_parallel = bool(enabled)
-        self._slice_parallel_group = group
+    def enable_slice_parallel(self, group=None, enabled=True, mode='auto', chunks=None, output='replicated', stats=None):
+        """Shard the slice axis of the embedding over the ranks of `group` (dist.py).
+
+        mode    'gather'    all-gather of the embedding blocks (bit-identical to one GPU), the tail replicated;
+                'consumer'  the first Linear layer stays sharded: partial sums reduce-scattered, finished rows all-gathered
+                            (needs the fused configuration; raises otherwise);
+                'auto'      consumer where it applies, else gather.  Training always takes the differentiable gather form.
+        chunks  node-range chunks of the pipeline (collective of chunk c under the kernels of chunk c + 1); default by size.
+        output  'replicated' (the reference's contract: every rank returns all rows) or, consumer form only, 'sharded':
+                returns (rows [chunks, chunk_rows / world, out], first_row [chunks]) -- this rank's finished rows.
+        stats   optional dict that every forward fills with the form taken and the bytes each rank sent."""
+        assert mode in ('auto', 'gather', 'consumer') and output in ('replicated', 'sharded')
+        self._slice_parallel = dict(group=group, mode=mode, chunks=chunks, output=output, stats=stats) if enabled else None
         return self
 
     # the reference defines these as empty stubs and never calls propagate() (fsw_conv.py:374-381)
@@ -440,9 +521,17 @@ class FSW_readout(FSW_conv):
         assert vertex_features.device == emb_mod.get_device() and graph_index.device == emb_mod.get_device()
         assert vertex_features.dtype == emb_mod.get_dtype()
         src = torch.arange(num_vertices, device=vertex_features.device, dtype=torch.int64)
+        if batch_size == 0 or num_vertices == 0:
+            return torch.zeros((batch_size, self.out_channels), dtype=vertex_features.dtype, device=vertex_features.device)
         graph = build_csr(graph_index.contiguous(), src, None, batch_size, num_vertices)
-        emb = torch.empty((batch_size, self.embed_dim), dtype=vertex_features.dtype, device=vertex_features.device)
-        emb_mod.embed_into(vertex_features.contiguous(), graph, emb)
+        needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            # training: the same differentiable embedding as FSW_conv (the reference readout is differentiable through
+            # self.fsw_embed, fsw_conv.py:503-515); readout segments are long rows, covered by the long-row backward kernels
+            emb = emb_mod.embed_autograd(vertex_features.contiguous(), graph)
+        else:
+            emb = torch.empty((batch_size, self.embed_dim), dtype=vertex_features.dtype, device=vertex_features.device)
+            emb_mod.embed_into(vertex_features.contiguous(), graph, emb)
         if graph.flags & 1:
             raise AssertionError('all entries of graph_index must be in the range 0,...,batch_size-1')
         if self.mlp is not None:

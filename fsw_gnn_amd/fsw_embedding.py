@@ -16,10 +16,12 @@ Not implemented (raise NotImplementedError): Cartesian mode (nSlices x nFreqs), 
 """
 import ctypes
 import numbers
+import struct
 
 import numpy as np
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from .coherence import minimize_mutual_coherence
@@ -51,62 +53,75 @@ class _EmbedGraphFn(torch.autograd.Function):
     Every weight mode and degree class is supported (unit-weight register rows use the float64 coefficient tables, weighted
     rows and rows above 32 neighbours evaluate the coefficients in float64 on the fly); the weights themselves are
     constants (no gradient w.r.t. W); the 'homog' mass encodings are differentiated by embed_autograd on top of this.
+
+    slice_range = (ka, kb): only slices ka..kb-1 (multi-GPU slice sharding, dist.py): the output is
+    [mass column | slices ka..kb-1] and the parameter gradients are full-size tensors that are zero outside the block.
+    With `group` the block gradients of all ranks are summed by all_reduce inside backward, so that every rank ends with
+    the gradients one GPU would compute (the mass column, replicated on every rank, is counted once).
     """
 
     @staticmethod
-    def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale):
+    def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale, slice_range, group):
+        ka, kb = (0, module.nSlices) if slice_range is None else slice_range
+        has_mass = 1 if module.encode_total_mass else 0
         with torch.no_grad():
             # 'homog' / 'homog_alt': embed_autograd asks for the 'plain' embedding (module._force_plain) and applies the
             # epilogue with differentiable torch ops on top of it
             assert (not module.encode_total_mass) or module.total_mass_encoding_method == 'plain' or module._force_plain
-            prepared = module.prepare(X, graph)
-            out = torch.empty((graph.num_rows, module.d_out), dtype=X.dtype, device=X.device)
+            prepared = module.prepare(X, graph, slice_range=slice_range)
+            out = torch.empty((graph.num_rows, has_mass + kb - ka), dtype=X.dtype, device=X.device)
             module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
         ctx.module, ctx.graph, ctx.prepared, ctx.out_scale = module, graph, prepared, float(out_scale)
+        ctx.slice_range, ctx.group = (ka, kb), group
         ctx.num_edge_rows = 0 if edge_feat is None else edge_feat.shape[0]
         ctx.save_for_backward(X, projVecs, freqs)
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         module, graph, prepared, out_scale = ctx.module, ctx.graph, ctx.prepared, ctx.out_scale
-        X, V, freqs = ctx.saved_tensors
+        X, Vfull, freqs_full = ctx.saved_tensors
+        ka, kb = ctx.slice_range
+        group = ctx.group
+        sharded = group is not None
         L = _lib.lib()
-        S, has_mass = module.nSlices, (1 if module.encode_total_mass else 0)
+        S, has_mass = kb - ka, (1 if module.encode_total_mass else 0)
+        V = Vfull.detach()[ka:kb]
+        fr = freqs_full.detach()[ka:kb].contiguous()
         g = g.contiguous()
         stream = torch.cuda.current_stream(X.device).cuda_stream
         ldp, Xp, table, st = prepared["ldp"], prepared["Xp"], prepared["table"], prepared["stats"]
         gX = gV = gfreqs = gbias = gscale = None
         need_xp = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         gEf = None
-        if graph.ef is not None and (need_xp or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]):
+        gVb = gfb = None          # block gradients (rows ka..kb-1 of projVecs, entries ka..kb-1 of freqs)
+        if S > 0 and graph.ef is not None and (need_xp or ctx.needs_input_grad[2] or ctx.needs_input_grad[5]):
             # edge features: the kernels store the gradient of every key; everything else is index_add + three GEMMs
             nnz = st[_lib.STAT_NNZ]
-            fr = freqs.detach()
             scratch = None
             if st[_lib.STAT_NUM_GLOBAL] > 0:
                 scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=X.device)
             gkey = torch.zeros((max(nnz, 1), S), dtype=torch.float32, device=X.device)
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
-            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch)
+            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch, slice_offset=ka)
             _lib.check(L.fsw_embed_backward_keys_f32(ctypes.byref(a), _lib.ptr(g), g.stride(0), _lib.ptr(gkey), S, _lib.ptr(gf), stream),
                        "fsw_embed_backward_keys_f32")
-            gkey, ef, Vd = gkey[:nnz], graph.ef[:nnz], V.detach()
+            gkey, ef = gkey[:nnz], graph.ef[:nnz]
             if need_xp:
                 gXp = torch.zeros((X.shape[0], S), dtype=torch.float32, device=X.device).index_add_(0, graph.col[:nnz].long(), gkey)
                 if ctx.needs_input_grad[0]:
-                    gX = gXp @ Vd[:, :module.d_in]
+                    gX = gXp @ V[:, :module.d_in]
                 if ctx.needs_input_grad[1]:
-                    gV = torch.cat([gXp.t() @ X.detach(), gkey.t() @ ef], dim=1)
+                    gVb = torch.cat([gXp.t() @ X.detach(), gkey.t() @ ef], dim=1)
             if ctx.needs_input_grad[2]:
-                gfreqs = gf
+                gfb = gf
             if ctx.needs_input_grad[5]:
                 slot = graph.slot_of_edge[:edge_feat_rows(ctx)].long()
-                gslots = gkey @ Vd[:, module.d_in:]
+                gslots = gkey @ V[:, module.d_in:]
                 gEf = torch.where((slot >= 0)[:, None], gslots[slot.clamp(min=0)], torch.zeros((), device=X.device))
-        elif need_xp or ctx.needs_input_grad[2]:
+        elif S > 0 and (need_xp or ctx.needs_input_grad[2]):
             gXp = torch.zeros((X.shape[0], ldp), dtype=torch.float32, device=X.device)
-            fr = freqs.detach()
             dtable = None
             if prepared["unit_fast"]:
                 dtable = torch.empty_like(table)
@@ -115,17 +130,34 @@ class _EmbedGraphFn(torch.autograd.Function):
             if st[_lib.STAT_NUM_GLOBAL] > 0:
                 scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=X.device)
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
-            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch)
+            a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch, slice_offset=ka)
             _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
                                                 _lib.ptr(gf), stream), "fsw_embed_backward_f32")
             if ctx.needs_input_grad[0]:
-                gX = gXp[:, :S] @ V.detach()[:, :module.d_in]
+                gX = gXp[:, :S] @ V[:, :module.d_in]
             if ctx.needs_input_grad[1]:
-                gV = gXp[:, :S].t() @ X.detach()
+                gVb = gXp[:, :S].t() @ X.detach()
             if ctx.needs_input_grad[2]:
-                gfreqs = gf
+                gfb = gf
+        # block gradients -> full-size parameter gradients (zero outside the block), summed over the ranks when sharded
+        if ctx.needs_input_grad[0] and gX is None:
+            gX = torch.zeros_like(X)
+        if ctx.needs_input_grad[5] and gEf is None:
+            gEf = torch.zeros((edge_feat_rows(ctx), module.d_edge), dtype=X.dtype, device=X.device)
+        if ctx.needs_input_grad[1]:
+            gV = torch.zeros_like(Vfull)
+            if gVb is not None:
+                gV[ka:kb] = gVb
+        if ctx.needs_input_grad[2]:
+            gfreqs = torch.zeros_like(freqs_full)
+            if gfb is not None:
+                gfreqs[ka:kb] = gfb
         if ctx.needs_input_grad[3]:
-            gbias = out_scale * g[:, :module.d_out].sum(dim=0)
+            gbias = torch.zeros(has_mass + module.nSlices, dtype=g.dtype, device=g.device)
+            gb = out_scale * g.sum(dim=0)
+            if has_mass and ((not sharded) or dist_rank(group) == 0):
+                gbias[0] = gb[0]                       # replicated column: counted once in the sum over the ranks
+            gbias[has_mass + ka:has_mass + kb] = gb[has_mass:]
         if ctx.needs_input_grad[4]:
             deg = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
             if graph.w is None:
@@ -135,8 +167,18 @@ class _EmbedGraphFn(torch.autograd.Function):
                 m = torch.zeros(graph.num_rows, dtype=torch.float32, device=X.device).index_add_(0, rows, graph.w[:rows.numel()])
             fn = module.total_mass_encoding_function
             fm = m if fn == 'identity' else (2 * (m / (torch.sqrt(m + 1) + 1)) if fn == 'sqrt' else torch.log1p(m))
-            gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())
-        return gX, gV, gfreqs, gbias, gscale, gEf, None, None, None
+            gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())     # identical on every rank: no reduction
+        if sharded:
+            import torch.distributed as dist
+            for t in (gX, gV, gfreqs, gbias, gEf):
+                if t is not None:
+                    dist.all_reduce(t, group=group)
+        return gX, gV, gfreqs, gbias, gscale, gEf, None, None, None, None, None
+
+
+def dist_rank(group):
+    import torch.distributed as dist
+    return dist.get_rank(group)
 
 
 class FSW_embedding(nn.Module):
@@ -317,14 +359,6 @@ class FSW_embedding(nn.Module):
     def get_device(self):
         return self.projVecs.device
 
-    def _mass_scale_host(self):
-        """Host value of the total-mass scale, re-read from the device only when the parameter changed."""
-        p = self.total_mass_encoding_scale
-        key = (p.data_ptr(), p._version)
-        if getattr(self, '_mass_scale_cache', (None, None))[0] != key:
-            self._mass_scale_cache = (key, float(p.detach()))
-        return self._mass_scale_cache[1]
-
     def get_dtype(self):
         return self.projVecs.dtype
 
@@ -374,14 +408,25 @@ class FSW_embedding(nn.Module):
             if torch.is_tensor(W):
                 assert (len(W.shape) == len(X.shape) - 1) and (tuple(W.shape) == tuple(X.shape[0:-1])), \
                     "Shape mismatch between X and W: If X.shape = (b1,b2,...,bk,n,d_in) then W.shape should be (b1,b2,...,bk,n) (unless graph_mode=True)"
-                assert not W.is_sparse, "sparse W requires graph_mode=True in this build"
-                wvals = W.reshape(-1)
+                wvals = None if W.is_sparse else W.reshape(-1)
             elif W == 'unit':
                 wvals = None
             else:  # 'uniform'
                 wvals = torch.full((B * n,), 1.0 / n, dtype=self.get_dtype(), device=X.device)
-            rec = torch.arange(B, device=X.device, dtype=torch.int64).repeat_interleave(n)
-            snd = torch.arange(B * n, device=X.device, dtype=torch.int64)
+            if torch.is_tensor(W) and W.is_sparse:
+                # coalesced COO weights (reference fsw_embedding.py:664-668 accepts them in both modes): entry (b.., j)
+                # is element j of multiset b; absent entries are absent elements (weight 0)
+                idx, wvals = W.indices(), W.values()
+                if batch_dims:
+                    strides = torch.tensor(list(np.cumprod((batch_dims + (1,))[::-1])[::-1][1:]), device=X.device, dtype=torch.int64)
+                    rec = (idx[:len(batch_dims)] * strides[:, None]).sum(0)
+                else:
+                    rec = torch.zeros(idx.shape[1], device=X.device, dtype=torch.int64)
+                snd = (rec * n + idx[-1]).contiguous()
+                rec = rec.contiguous()
+            else:
+                rec = torch.arange(B, device=X.device, dtype=torch.int64).repeat_interleave(n)
+                snd = torch.arange(B * n, device=X.device, dtype=torch.int64)
             Xf = X.reshape(B * n, d)
             num_rows, out_shape = B, batch_dims
         else:
@@ -417,6 +462,12 @@ class FSW_embedding(nn.Module):
             Xf = X.reshape(B * n, d)
             num_rows, out_shape = B * nR, batch_dims + (nR,)
 
+        if num_rows == 0 or Xf.shape[0] == 0:
+            # nothing to embed / empty multisets only: the reference returns an empty tensor, resp. the embedding of the
+            # pad element alone; the kernels need at least one row and one point
+            if num_rows == 0:
+                return torch.zeros(out_shape + (self.d_out,), dtype=X.dtype, device=X.device)
+            Xf = torch.zeros((1, d), dtype=X.dtype, device=X.device)
         if self.d_edge > 0:
             graph = build_csr_coalesced(rec, snd, wvals.contiguous(), efvals.contiguous(), num_rows, Xf.shape[0])
         else:
@@ -428,18 +479,21 @@ class FSW_embedding(nn.Module):
             self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
         return out.reshape(out_shape + (self.d_out,))
 
-    def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None):
+    def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None, slice_range=None, group=None):
         """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn.  edge_feat: the per-input-edge
-        feature tensor the graph was coalesced from (its gradient is routed back through graph.slot_of_edge)."""
+        feature tensor the graph was coalesced from (its gradient is routed back through graph.slot_of_edge).
+        slice_range / group: this rank's block of slices under slice sharding (dist.py)."""
         bias = self.bias if self.enable_bias else None
         scale = self.total_mass_encoding_scale if self.encode_total_mass else None
         if (not self.encode_total_mass) or self.total_mass_encoding_method == 'plain':
-            return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale)
+            return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale, slice_range, group)
+        if slice_range is not None:
+            raise NotImplementedError("slice sharding supports total_mass_encoding_method='plain' only")
         # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): the 'plain' embedding without bias from the
         # kernels, then the same epilogue as embed_into(), out of place so that autograd differentiates it
         self._force_plain = True
         try:
-            P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale)
+            P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale, None, None)
         finally:
             self._force_plain = False
         tm = P[:, 0:1] / out_scale
@@ -454,27 +508,37 @@ class FSW_embedding(nn.Module):
         return out + out_scale * bias if bias is not None else out
 
     # ------------------------------------------------------------------------------------------------
-    _slice_offset = 0   # first slice of the block being processed (slice sharding / serialize_num_slices)
     _force_plain = False   # embed_autograd: 'plain' mass column and no bias from the kernels, epilogue in torch
 
-    def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None):
-        """Projection of all slices + (unit weights) coefficient table + the one device->host stats read.
+    def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None, slice_range=None):
+        """Projection of a block of slices (default: all) + (unit weights) coefficient table + the one device->host stats
+        read of the forward.
 
         linear2 = (W2 [H2, d_in] contiguous, b2 [H2] or None, Y2 [n, H2]): the projection GEMM also writes
         Y2[graph.invperm[i]] = X[i] . W2^T + b2, the vertex-feature half of FSW_conv's first Linear layer in the
         row order of the degree bins (csrc/conv_fused.hip reads it back as contiguous runs).
+        x_copy (optional [num_cols, d_in] view with unit inner stride): the projection kernel also stores X there
+        (FSW_conv's concat buffer, reference fsw_conv.py:357-358).
 
         Returns a dict that embed_into(prepared=...) or FSW_conv's fused Linear path consume.  Input validation
         (reference fsw_embedding.py:652-703) happens here: the kernels set flag bits, the host reads them once.
         """
         L = _lib.lib()
         dev = X.device
-        S = self.nSlices
+        ka, kb = (0, self.nSlices) if slice_range is None else slice_range
+        assert 0 <= ka <= kb <= self.nSlices, 'bad slice_range'
+        S = kb - ka
         assert X.is_contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
+        unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0
+        if S == 0:      # a rank without slices (more ranks than slices): only the stats
+            if x_copy is not None:
+                x_copy.copy_(X)
+            return {"Xp": None, "ldp": 0, "table": None, "stats": self._checked_stats(graph), "unit_fast": unit_fast,
+                    "slice_range": (ka, kb)}
         ldp = _round_up(S, 64)
         Xp = torch.empty((X.shape[0], ldp), dtype=torch.float32, device=dev)
-        V = self.projVecs.detach()
+        V = self.projVecs.detach()[ka:kb]
         if linear2 is not None:
             W2, b2, Y2 = linear2
             assert x_copy is None and W2.is_contiguous() and W2.shape[1] == self.d_in and Y2.stride(1) == 1
@@ -486,18 +550,23 @@ class FSW_embedding(nn.Module):
                                    ldp, _lib.ptr(x_copy), x_copy.stride(0) if x_copy is not None else 0,
                                    _lib.ptr(graph.stats_dev), stream)
         _lib.check(rc, "fsw_project_f32")
-        unit_fast = graph.w is None and self.total_mass_pad_thresh <= 1.0
         table = None
         if unit_fast:
             table = torch.empty((int(L.fsw_unit_table_rows(_lib.REG_MAX_DEG)), ldp), dtype=torch.float32, device=dev)
-            rc = L.fsw_unit_coeff_table(_lib.ptr(self.freqs.detach()), S, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
+            fr = self.freqs.detach()[ka:kb]
+            rc = L.fsw_unit_coeff_table(_lib.ptr(fr), S, _lib.REG_MAX_DEG, _lib.ptr(table), ldp, stream)
             _lib.check(rc, "fsw_unit_coeff_table")
         st = self._checked_stats(graph)
-        return {"Xp": Xp, "ldp": ldp, "table": table, "stats": st, "unit_fast": unit_fast}
+        return {"Xp": Xp, "ldp": ldp, "table": table, "stats": st, "unit_fast": unit_fast, "slice_range": (ka, kb)}
 
-    @staticmethod
-    def _checked_stats(graph):
-        st = graph.stats()
+    def _checked_stats(self, graph):
+        """The one device->host copy of a forward: validation flags, degree-class counts and -- parked in the spare stats
+        word right before the copy -- the current value of the total-mass scale (read from the parameter every time: no
+        host-side cache that an in-place edit of .data could outdate)."""
+        if self.encode_total_mass:
+            graph.stats_dev[_lib.STAT_USER:_lib.STAT_USER + 1].view(torch.float32).copy_(
+                self.total_mass_encoding_scale.detach().reshape(1).to(torch.float32))
+        st = graph.read_stats()
         if fsw_embedding_basic_safety_checks:
             fl = st[_lib.STAT_FLAGS]
             assert not (fl & _lib.FLAG_INDEX_RANGE), "adjacency index out of range"
@@ -506,29 +575,40 @@ class FSW_embedding(nn.Module):
             assert not (fl & _lib.FLAG_W_NEGATIVE), "All entries of W must be nonnegative"
         return st
 
-    def make_args(self, graph, st, Xp, ldp, freqs, S, table, out_ptr, ldo, bias_ptr, out_scale, has_mass, scratch=None):
+    def make_args(self, graph, st, Xp, ldp, freqs, S, table, out_ptr, ldo, bias_ptr, out_scale, has_mass, scratch=None,
+                  slice_offset=0, chunk=None):
+        """struct fsw_embed_args for one call.  chunk = c restricts the call to the recipients of row chunk c of a graph
+        built with chunk_rows > 0 (graph.py)."""
         a = _lib.EmbedArgs()
         a.rowptr, a.col = graph.rowptr.data_ptr(), graph.col.data_ptr()
         a.w = graph.w.data_ptr() if graph.w is not None else None
-        a.perm, a.bin_start, a.num_rows = graph.perm.data_ptr(), graph.bin_start.data_ptr(), graph.num_rows
+        a.perm = graph.perm.data_ptr()
+        if chunk is None:
+            assert graph.num_chunks == 1, 'a graph with row chunks is consumed chunk by chunk'
+            a.bin_start, rows = graph.bin_start.data_ptr(), graph.num_rows
+        else:
+            a.bin_start = graph.bin_start.view(-1, _lib.NUM_BINS + 1)[chunk].data_ptr()
+            rows = min(graph.chunk_rows, graph.num_rows - chunk * graph.chunk_rows) if graph.chunk_rows else graph.num_rows
+        a.num_rows = rows
         a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, freqs.data_ptr(), S, float(self.total_mass_pad_thresh)
         a.unit_table, a.ldt = (table.data_ptr() if table is not None else None), ldp
         a.out, a.ldo, a.bias = out_ptr, ldo, bias_ptr
         a.out_scale, a.has_mass = float(out_scale), has_mass
         a.mass_fn = _MASS_FN[self.total_mass_encoding_function]
-        a.mass_scale = self._mass_scale_host() if self.encode_total_mass else 1.0
-        a.num_reg_rows, a.num_lds_rows = st[_lib.STAT_NUM_REG], st[_lib.STAT_NUM_LDS]
-        a.num_global_rows, a.num_zero_rows = st[_lib.STAT_NUM_GLOBAL], st[_lib.STAT_NUM_ZERO]
+        a.mass_scale = struct.unpack('f', struct.pack('i', st[_lib.STAT_USER]))[0] if self.encode_total_mass else 1.0
+        a.num_reg_rows, a.num_lds_rows = min(st[_lib.STAT_NUM_REG], rows), min(st[_lib.STAT_NUM_LDS], rows)
+        a.num_global_rows, a.num_zero_rows = min(st[_lib.STAT_NUM_GLOBAL], rows), min(st[_lib.STAT_NUM_ZERO], rows)
         a.max_degree = st[_lib.STAT_MAX_DEGREE]
         a.scratch = scratch.data_ptr() if scratch is not None else None
         a.scratch_bytes = scratch.numel() if scratch is not None else 0
         if graph.ef is not None:            # edge features: Ve = projVecs[:, d_in:], read in place (row stride d_in + d_edge)
             V = self.projVecs.detach()
             a.efeat, a.d_edge = graph.ef.data_ptr(), self.d_edge
-            a.Ve, a.ldve = V.data_ptr() + 4 * (self._slice_offset * V.stride(0) + self.d_in), V.stride(0)
+            a.Ve, a.ldve = V.data_ptr() + 4 * (slice_offset * V.stride(0) + self.d_in), V.stride(0)
         return a
 
-    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None, prepared=None):
+    def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None,
+                   prepared=None, chunks=None):
         """Writes out_scale * E(X, graph) into the left columns of `out` (row stride out.stride(0)).
 
         X [num_cols, d_in] float32 contiguous; out [num_rows, >= width] float32 with unit inner stride, where
@@ -536,6 +616,7 @@ class FSW_embedding(nn.Module):
         slices (multi-GPU slice sharding, dist.py: column 0 is still the total-mass column, then slices ka..kb-1).
         x_copy (optional [num_cols, d_in] view with unit inner stride): the projection kernel also stores X there
         (FSW_conv's concat buffer, reference fsw_conv.py:357-358).
+        prepared: the result of prepare() (its slice_range is used); chunks: row chunks to process (default all).
         This is the hot path: projection (MFMA) -> coefficient table -> fused neighbourhood kernels.
         """
         L = _lib.lib()
@@ -543,6 +624,9 @@ class FSW_embedding(nn.Module):
         has_mass = 1 if self.encode_total_mass else 0
         if x_copy is not None:
             assert x_copy.shape == X.shape and x_copy.stride(1) == 1 and x_copy.dtype == X.dtype
+        if prepared is not None:
+            assert slice_range is None or tuple(slice_range) == tuple(prepared["slice_range"])
+            slice_range = prepared["slice_range"]
         ka, kb = (0, self.nSlices) if slice_range is None else slice_range
         assert 0 <= ka < kb <= self.nSlices or self.d_out == 0, 'bad slice_range'
         S = kb - ka
@@ -565,7 +649,7 @@ class FSW_embedding(nn.Module):
         step = S if (serialize_num_slices is None or serialize_num_slices >= S) else int(serialize_num_slices)
         assert step >= 1, 'serialize_num_slices must be None or a positive integer'
         if prepared is not None:
-            assert step == S and not partial, 'a prepared projection covers all slices in one chunk'
+            assert step == S, 'a prepared projection covers its slices in one chunk'
             ldp, Xp, table, st = prepared["ldp"], prepared["Xp"], prepared["table"], prepared["stats"]
         else:
             ldp = _round_up(step, 64)
@@ -578,11 +662,12 @@ class FSW_embedding(nn.Module):
         freqs = self.freqs.detach()[ka:kb]
         scratch = None
         assert (graph.ef is None) == (self.d_edge == 0), 'edge features must be given exactly when d_edge > 0'
+        if chunks is None:
+            chunks = [None] if graph.num_chunks == 1 and not graph.chunk_rows else range(graph.num_chunks)
         for k0 in range(0, S, step):
             k1 = min(S, k0 + step)
             Sc = k1 - k0
             fc = freqs[k0:k1]
-            self._slice_offset = ka + k0
             if prepared is None:
                 Vc = V[k0:k1]
                 rc = L.fsw_project_f32(_lib.ptr(X), X.shape[0], self.d_in, X.stride(0), _lib.ptr(Vc), Sc, Vc.stride(0),
@@ -600,11 +685,12 @@ class FSW_embedding(nn.Module):
             first = (k0 == 0)
             hm = has_mass if first else 0          # the first chunk also writes the total-mass column
             col0 = 0 if first else has_mass + k0   # first destination column of this chunk
-            a = self.make_args(graph, st, Xp, ldp, fc, Sc, table, out.data_ptr() + 4 * col0, out.stride(0),
-                               (bias.data_ptr() + 4 * col0) if bias is not None else None, out_scale, hm, scratch)
-            rc = L.fsw_embed_f32(ctypes.byref(a), stream)
-            _lib.check(rc, "fsw_embed_f32")
-        self._slice_offset = 0
+            for c in chunks:
+                a = self.make_args(graph, st, Xp, ldp, fc, Sc, table, out.data_ptr() + 4 * col0, out.stride(0),
+                                   (bias.data_ptr() + 4 * col0) if bias is not None else None, out_scale, hm, scratch,
+                                   slice_offset=ka + k0, chunk=c)
+                rc = L.fsw_embed_f32(ctypes.byref(a), stream)
+                _lib.check(rc, "fsw_embed_f32")
 
         if not plain:
             # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): rarely used epilogues, done with

@@ -18,8 +18,11 @@ class CSRGraph:
     """
 
     def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None, ef=None,
-                 slot_of_edge=None):
+                 slot_of_edge=None, chunk_rows=0):
         self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
+        # chunk_rows > 0: bin_start is [num_chunks, NUM_BINS + 1], rows binned per chunk of chunk_rows consecutive rows
+        self.chunk_rows = chunk_rows
+        self.num_chunks = -(-num_rows // chunk_rows) if chunk_rows else 1
         self.rowptr, self.col, self.w, self.perm, self.bin_start = rowptr, col, w, perm, bin_start
         self.stats_dev = stats_dev
         self.invperm = invperm
@@ -27,11 +30,19 @@ class CSRGraph:
         self.slot_of_edge = slot_of_edge    # int32[num_input_edges]: CSR entry of every input edge (coalesced build)
         self._stats = None
 
-    def stats(self):
-        """Host copy of the stats words (one small device->host copy; synchronises the stream)."""
-        if self._stats is None:
-            self._stats = self.stats_dev.cpu().tolist()
+    def read_stats(self):
+        """Fresh host copy of the stats words (one small device->host copy; synchronises the stream)."""
+        self._stats = self.stats_dev.cpu().tolist()
         return self._stats
+
+    def stats(self):
+        """Host copy of the stats words as of the last read_stats() (read now if there was none)."""
+        return self._stats if self._stats is not None else self.read_stats()
+
+    def clear_input_flags(self):
+        """A graph reused for another forward (FSW_conv.cache_graph): forget what earlier inputs set (X non-finite)."""
+        self.stats_dev[_lib.STAT_FLAGS:_lib.STAT_FLAGS + 1].bitwise_and_(~_lib.FLAG_X_NONFINITE)
+        self._stats = None
 
     @property
     def flags(self):
@@ -46,8 +57,16 @@ class CSRGraph:
         return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
 
 
-def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False):
-    """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights)."""
+def round_chunk_rows(rows, multiple_of=1):
+    """Smallest legal chunk_rows >= rows: a multiple of BIN_BLOCK_ROWS (graph_build.hip) and of `multiple_of`."""
+    import math
+    m = math.lcm(_lib.BIN_BLOCK_ROWS, int(multiple_of))
+    return max(1, -(-int(rows) // m)) * m
+
+
+def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False, chunk_rows=0):
+    """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights).
+    chunk_rows > 0: degree bins per chunk of chunk_rows consecutive rows (include/fsw_hip.h, fsw_graph_build)."""
     L = _lib.lib()
     dev = recipients.device
     if dev.type != "cuda":
@@ -65,16 +84,19 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     w = torch.empty(max(E, 1), dtype=torch.float32, device=dev) if edge_w is not None else None
     perm = torch.empty(num_rows, dtype=torch.int32, device=dev)
     invperm = torch.empty(num_rows, dtype=torch.int32, device=dev) if want_invperm else None
-    bin_start = torch.empty(_lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
+    num_chunks = -(-num_rows // chunk_rows) if chunk_rows else 1
+    assert num_chunks <= _lib.MAX_ROW_CHUNKS and chunk_rows % _lib.BIN_BLOCK_ROWS == 0, "bad chunk_rows"
+    bin_start = torch.empty((num_chunks, _lib.NUM_BINS + 1), dtype=torch.int32, device=dev)
     stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
     ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = L.fsw_graph_build(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols,
+    rc = L.fsw_graph_build(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols, chunk_rows,
                            _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
                            _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
-    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, invperm)
+    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start if chunk_rows else bin_start.view(-1), stats, invperm,
+                    chunk_rows=chunk_rows)
 
 
 def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_cols, want_slots=False):

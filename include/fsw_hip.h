@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
 
-#define FSW_ABI_VERSION 2
+#define FSW_ABI_VERSION 3
 
 /* Degree classes of the fused neighbourhood kernels.  Rows are binned by in-degree:
  *   bin b, 0 <= b <= FSW_REG_MAX_DEG : rows of degree exactly b (register path, one wave per row and
@@ -66,6 +66,8 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
 #define FSW_STAT_NUM_LDS 4      /* rows with FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (mid bins + LDS bin) */
 #define FSW_STAT_NUM_GLOBAL 5
 #define FSW_STAT_NNZ 6          /* fsw_graph_build_coalesced: number of CSR entries after coalescing */
+#define FSW_STAT_USER 7         /* never written by the library after the build zeroes it: the Python side parks the bits of
+                                   the total-mass scale here so that ONE device->host copy per forward fetches everything */
 #define FSW_NUM_STATS 8
 
 #define FSW_FLAG_INDEX_RANGE 1   /* an edge endpoint outside [0, num_rows) x [0, num_cols) */
@@ -88,10 +90,18 @@ const char* fsw_last_error(void); /* host string, valid until the next failing c
  *   rowptr int32[num_rows+1], col int32[num_edges], w float[num_edges] (ignored if edge_w NULL)
  *   perm int32[num_rows]  rows ordered by degree bin; bin_start int32[FSW_NUM_BINS+1] offsets into perm
  *   invperm int32[num_rows] or NULL: position of every row in perm (perm[invperm[r]] == r)
- *   stats int32[FSW_NUM_STATS] (zeroed by this call)                                               */
+ *   stats int32[FSW_NUM_STATS] (zeroed by this call)
+ *   chunk_rows : 0, or a positive multiple of FSW_BIN_BLOCK_ROWS.  With chunk_rows > 0 the rows are binned separately
+ *                inside every chunk of chunk_rows consecutive rows: perm lists chunk 0's rows by degree bin, then chunk
+ *                1's, ...; bin_start then holds ceil(num_rows / chunk_rows) (<= FSW_MAX_ROW_CHUNKS) rows of
+ *                FSW_NUM_BINS + 1 offsets.  Passing row c of bin_start (and num_rows = chunk_rows) to fsw_embed_f32 /
+ *                fsw_conv_fused_f32 restricts that call to the recipients of chunk c -- the multi-GPU path overlaps
+ *                the collective of one node range with the kernels of the next this way.                          */
+#define FSW_BIN_BLOCK_ROWS 2048
+#define FSW_MAX_ROW_CHUNKS 256
 size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges);
 int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w,
-                    int64_t num_edges, int64_t num_rows, int64_t num_cols,
+                    int64_t num_edges, int64_t num_rows, int64_t num_cols, int64_t chunk_rows,
                     int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* invperm, int32_t* bin_start,
                     int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
 
@@ -193,6 +203,14 @@ int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
  *   the kernel prefetches past the end), j < ldw (Hout rounded up to 32), K = has_mass + S, h in {0,1},
  *   i in {0..3}; 16-byte aligned.                                                                      */
 size_t fsw_conv_fused_lds_bytes(int S, int has_mass);
+/* Packs K columns of W [Hout, ldw_in] starting at column col0 (= the W1 block that multiplies the embedding columns
+ * a call of fsw_conv_fused_f32 produces: the whole embedding on one GPU, one rank's [mass |] slice block under slice
+ * sharding) into Wq (fsw_packed_linear_floats(K, Hout) floats, 16-byte aligned, layout above) and, when W2out != NULL,
+ * copies the d2 columns of W2 (a pointer INTO W, row stride ldw_in) to W2out [Hout, ldw2out].  One launch per
+ * forward: nothing is cached on the host, so in-place edits of the weights are always seen.                        */
+size_t fsw_packed_linear_floats(int K, int Hout);
+int fsw_pack_linear_f32(const float* W, int64_t ldw_in, int Hout, int col0, int K, float* Wq, const float* W2, int d2,
+                        float* W2out, int64_t ldw2out, fsw_stream_t stream);
 int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
                            float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
                            int64_t ldy2, const int32_t* row_map, int32_t* stats, fsw_stream_t stream);

@@ -461,6 +461,85 @@ def test_readout_layer(dev):
     assert np.abs(out[3]).max() == 0.0
 
 
+def test_readout_layer_is_differentiable(dev):
+    """Training through FSW_readout (reference fsw_conv.py:503-515 is differentiable through self.fsw_embed): gradients
+    of the vertex features and of the slices / frequencies against the oracle's analytic backward."""
+    from fsw_gnn_amd import FSW_readout
+    rng = np.random.default_rng(14)
+    sizes = [40, 1, 300, 0, 77, 2500]
+    n, d, out_ch = sum(sizes), 8, 12
+    gi = np.repeat(np.arange(len(sizes)), sizes).astype(np.int64)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    ro = FSW_readout(d, out_ch, concat_self=False, mlp_layers=0, bias=False, encode_vertex_degrees=False, device=dev)
+    assert ro.fsw_embed.projVecs.requires_grad and ro.fsw_embed.freqs.requires_grad
+    Xd = t(X, dev).requires_grad_(True)
+    out = ro(Xd, t(gi, dev, torch.int64), len(sizes))
+    assert out.grad_fn is not None
+    R = rng.standard_normal((len(sizes), out_ch))
+    (out * t(R, dev)).sum().backward()
+    V = ro.fsw_embed.projVecs.detach().cpu().numpy()
+    fr = ro.fsw_embed.freqs.detach().cpu().numpy()
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, np.arange(n), np.ones(n), V, fr, R, Xp_override=_hip_projection(ro.fsw_embed, Xd))
+    assert relerr(Xd.grad.cpu().numpy(), gX) < 2e-5
+    assert relerr(ro.fsw_embed.projVecs.grad.cpu().numpy(), gV) < 2e-5
+    assert relerr(ro.fsw_embed.freqs.grad.cpu().numpy(), gxi) < 2e-5
+    # an empty batch / no vertices at all: empty result instead of an error
+    with torch.no_grad():
+        assert tuple(ro(torch.zeros((0, d), device=dev), torch.zeros(0, dtype=torch.int64, device=dev), 0).shape) == (0, out_ch)
+
+
+def test_in_place_weight_edits_are_seen_and_graph_cache_is_safe(dev):
+    """Nothing derived from the parameters is cached on the host: edits through .data (which do not bump _version) change
+    the next forward; the optional CSR cache is keyed on the edge_index tensor itself and forgets old input flags."""
+    from fsw_gnn_amd import FSW_conv
+    n, E, d = 2000, 16000, 16
+    ei = t(cases.synth.er_multigraph(n, E, seed=3), dev, torch.int64)
+    X = t(cases.synth.features(n, d, seed=4), dev)
+    torch.manual_seed(0)
+    conv = FSW_conv(d, 8, embed_dim=33, device=dev)
+    conv2 = FSW_conv(d, 8, embed_dim=33, device=dev)
+    conv2.load_state_dict(conv.state_dict())
+    with torch.no_grad():
+        y0 = conv(X, ei)
+        conv.mlp[0].weight.data.mul_(2.0)                       # _version stays 0
+        conv.fsw_embed.total_mass_encoding_scale.data.fill_(3.0)
+        conv2.mlp[0].weight.mul_(2.0)
+        conv2.fsw_embed.total_mass_encoding_scale.fill_(3.0)
+        y1, y2 = conv(X, ei), conv2(X, ei)
+        assert not torch.allclose(y1, y0) and torch.equal(y1, y2)
+        conv.fuse_linear = False
+        assert float((conv(X, ei) - y1).abs().max()) < 1e-5 * float(y1.abs().max())
+        conv.fuse_linear = True
+        # CSR cache: same tensor -> hit; an equal-sized new tensor -> rebuilt; bad input once does not poison later calls
+        conv.cache_graph = True
+        ya = conv(X, ei)
+        g1 = conv._graph_cache[2]
+        assert conv(X, ei) is not None and conv._graph_cache[2] is g1
+        Xbad = X.clone()
+        Xbad[5, 3] = float("nan")
+        with pytest.raises(AssertionError, match="NaNs or infs"):
+            conv(Xbad, ei)
+        assert torch.equal(conv(X, ei), ya)                     # the flag of the bad input is gone
+        ei2 = ei.flip(1).contiguous()
+        yb = conv(X, ei2)
+        assert conv._graph_cache[2] is not g1 and float((yb - ya).abs().max()) < 1e-5 * float(ya.abs().max())
+        assert tuple(conv(torch.zeros((0, d), device=dev), torch.zeros((2, 0), dtype=torch.int64, device=dev)).shape) == (0, 8)
+
+
+def test_sparse_weights_outside_graph_mode(dev):
+    """Coalesced COO weights with graph_mode=False (reference fsw_embedding.py:664-668): same result as the dense tensor."""
+    rng = np.random.default_rng(6)
+    B, n, d, S = 3, 50, 7, 12
+    X = rng.standard_normal((B, n, d)).astype(np.float32)
+    W = (rng.random((B, n)) * (rng.random((B, n)) < 0.6)).astype(np.float32)
+    E = make_embedding(dev, cases.synth.unit_slices(S, d, seed=5), cases.random_freqs(S, seed=6), encode_total_mass=True)
+    with torch.no_grad():
+        dense = E(t(X, dev), t(W, dev))
+        sparse = E(t(X, dev), t(W, dev).to_sparse().coalesce())
+    assert tuple(dense.shape) == (B, S + 1) and float((dense - sparse).abs().max()) < 1e-6 * float(dense.abs().max())
+
+
 def test_er1m_config3_full_size(dev):
     """BASELINE config 3 at full size against rows sampled from the reference's float64 run."""
     g = golden("er1m")
@@ -913,27 +992,70 @@ ei = torch.from_numpy(synth.er_multigraph(n, E, seed=7)).to(dev)
 X = torch.from_numpy(synth.features(n, d, seed=8)).to(dev)
 torch.manual_seed(3)
 conv = FSW_conv(d, 12, embed_dim=31, device=dev)                   # 30 slices: uneven blocks over 4 ranks
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
 with torch.no_grad():
     ref = conv(X, ei)                                              # single-GPU fused path
     conv.fuse_linear = False
     ref_u = conv(X, ei)
-    conv.enable_slice_parallel(None)
-    y = conv(X, ei)                                                # slice-sharded: kernels on this rank's block + all-gather
+    conv.fuse_linear = True
+    # 1. gather form: this rank's block of slices + all-gather, pipelined over 2 node-range chunks
+    st = {}
+    conv.enable_slice_parallel(None, mode="gather", chunks=2, stats=st)
+    y = conv(X, ei)
+    assert st["mode"] == "gather" and st["collective"] == "all_gather", st
+    assert torch.equal(y, ref_u), float((y - ref_u).abs().max())  # no reduction anywhere: bit-identical to one GPU
+    conv.enable_slice_parallel(None, mode="gather", chunks=1)
+    assert torch.equal(conv(X, ei), ref_u)
+    # 2. sharded-consumer form: W1 column block inside the fused kernel, reduce-scatter of the partial sums
+    for chunks in (1, 2):
+        conv.enable_slice_parallel(None, mode="consumer", chunks=chunks, stats=st)
+        yc = conv(X, ei)
+        assert st["mode"] == "consumer" and st["collective"] == "reduce_scatter+all_gather", st
+        assert tuple(yc.shape) == tuple(ref.shape) and rel(yc, ref) < 1e-6, rel(yc, ref)   # sums over the ranks: order differs
+    conv.enable_slice_parallel(None, mode="consumer", chunks=2, output="sharded")
+    R, row0 = conv(X, ei)
+    m = R.shape[1]
+    for c in range(R.shape[0]):
+        r0 = int(row0[c]); r1 = min(r0 + m, n)
+        if r1 > r0:
+            assert rel(R[c, :r1 - r0], ref[r0:r1]) < 1e-6
+    # 3. auto on a graph with long rows: the consumer form does not apply, the gather form takes over
+    ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
+                     torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
+    conv.enable_slice_parallel(None, mode="auto", stats=st)
+    y2 = conv(X, ei2)
+    assert st["mode"] == "gather"
+    conv.enable_slice_parallel(None, enabled=False)
+    ref2 = conv(X, ei2)
+    assert rel(y2, ref2) < 1e-6
+    conv.enable_slice_parallel(None, mode="auto", stats=st)
+    ya = conv(X, ei)
+    assert st["mode"] == "consumer" and rel(ya, ref) < 1e-6
 torch.cuda.synchronize()
-assert torch.equal(y, ref_u), float((y - ref_u).abs().max())      # no reduction anywhere: bit-identical to one GPU
-assert float((y - ref).abs().max()) < 1e-5
-# node-range sharding: every rank runs the fused layer on its rows, one all-gather of the OUTPUT
+# 4. training in slice mode: gradients equal the single-GPU gradients on every rank
+def grads(sharded):
+    conv.enable_slice_parallel(None, enabled=sharded)
+    conv.zero_grad()
+    Xg = X.clone().requires_grad_(True)
+    out = conv(Xg, ei)
+    torch.manual_seed(11)
+    (out * torch.randn_like(out)).sum().backward()
+    ps = {k: p.grad.clone() for k, p in conv.named_parameters() if p.grad is not None}
+    ps["X"] = Xg.grad.clone()
+    return out.detach(), ps
+o1, g1 = grads(False)
+o2, g2 = grads(True)
+assert rel(o2, o1) < 1e-6
+assert set(g1) == set(g2) and {"fsw_embed.projVecs", "fsw_embed.freqs", "mlp.0.weight", "X"} <= set(g1), sorted(g1)
+for k in g1:
+    assert rel(g2[k], g1[k]) < 2e-4, (k, rel(g2[k], g1[k]))        # float atomics: the order of the sums differs run to run
 conv.enable_slice_parallel(None, enabled=False)
-conv.fuse_linear = True
+# node-range sharding (extra, behind its flag): every rank runs the fused layer on its rows, one all-gather of the OUTPUT
 conv.enable_node_parallel(None)
 with torch.no_grad():
     yn = conv(X, ei)
-    # a graph with long rows: the ranks owning them fall back to the unfused kernels for their block
-    ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
-                     torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
     yn2 = conv(X, ei2)
     conv.enable_node_parallel(None, enabled=False)
-    ref2 = conv(X, ei2)
 torch.cuda.synchronize()
 assert float((yn - ref).abs().max()) < 2e-6 * float(ref.abs().max())     # same kernel on the same rows; only x . W2^T comes from a BLAS GEMM here
 assert float((yn2 - ref2).abs().max()) < 2e-5 * float(ref2.abs().max())
@@ -945,8 +1067,8 @@ if rank == 0:
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_slice_parallel_conv_matches_single_gpu(dev, world, tmp_path):
-    """FSW_conv.enable_slice_parallel and enable_node_parallel over `world` ranks (gloo, ranks sharing the one GPU of the
-    test box)."""
+    """FSW_conv.enable_slice_parallel (gather / sharded-consumer / auto forms, inference and training) and
+    enable_node_parallel over `world` ranks (gloo, ranks sharing the one GPU of the test box)."""
     import os
     import subprocess
     import sys
@@ -975,6 +1097,15 @@ out = torch.empty((n, 1 + S + 5), device=dev)
 all_gather_slice_blocks(local, slice_partition(S, 1), 1, out)
 torch.cuda.synchronize()
 assert torch.equal(out[:, :1 + S], local)
+# the reduce-scatter / all-gather pipeline of the sharded-consumer form on the same backend (asynchronous collectives)
+from fsw_gnn_amd.dist import reduce_scatter_pipeline
+P = torch.randn((3 * 2048, 8), device=dev)
+def part(c, Pc): Pc.copy_(P[c * 2048:(c + 1) * 2048])
+def fin(r0, r1, R): R.mul_(2.0)
+st = {}
+Y = reduce_scatter_pipeline(part, fin, 3, 2048, 5000, 8, torch.float32, dev, None, "replicated", st)
+torch.cuda.synchronize()
+assert torch.equal(Y, 2.0 * P[:5000]) and st["collective"] == "reduce_scatter+all_gather"
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_OK")

@@ -111,35 +111,85 @@ _WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from fsw_gnn_amd.dist import slice_partition, all_gather_slice_blocks
+from fsw_gnn_amd.dist import slice_partition, all_gather_slice_blocks, pipelined_gather, reduce_scatter_pipeline
 from oracle import fsw_oracle as O
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 g = np.load(os.path.join(sys.argv[1], "tests", "golden", "tiny_graph.npz"))
-rp, cl, vv = O.csr_from_coo(g["adj_indices"][0], g["adj_indices"][1], g["adj_values"], 64)
+n = 64
+rp, cl, vv = O.csr_from_coo(g["adj_indices"][0], g["adj_indices"][1], g["adj_values"], n)
 S = g["V"].shape[0]
 parts = slice_partition(S, world)
 ka, kb = parts[rank]
 wmax = max(b - a for a, b in parts)
 # stand-in for the per-rank HIP call: the oracle restricted to this rank's block of slices (plus mass column)
 full = O.fsw_embedding_forward(g["X"], rp, cl, vv, g["V"], g["freqs"], encode_total_mass=True)
-local = np.zeros((64, 1 + wmax))
+local = np.zeros((n, 1 + wmax))
 local[:, 0] = full[:, 0]
 blk = O.fsw_embedding_forward(g["X"], rp, cl, vv, g["V"][ka:kb], g["freqs"][ka:kb])
 local[:, 1:1 + (kb - ka)] = blk
-out = torch.full((64, 1 + S + 3), -7.0, dtype=torch.float64)          # wider buffer, like FSW_conv's concat buffer
-all_gather_slice_blocks(torch.from_numpy(local).contiguous(), parts, 1, out)
+localt = torch.from_numpy(local).contiguous()
+
+# 1. gather form, one collective
+out = torch.full((n, 1 + S + 3), -7.0, dtype=torch.float64)          # wider buffer, like FSW_conv's concat buffer
+all_gather_slice_blocks(localt, parts, 1, out)
 err = float(np.abs(out[:, :1 + S].numpy() - full).max())
 assert err == 0.0, err                                               # no reduction: bit-identical reassembly
 assert (out[:, 1 + S:] == -7.0).all()
+
+# 2. gather form, pipelined over node-range chunks (ragged last chunk)
+for cs in (16, 24, 64):
+    nch = -(-n // cs)
+    out2 = torch.full((n, 1 + S + 3), -7.0, dtype=torch.float64)
+    def compute(c, lc):
+        r0, r1 = c * cs, min((c + 1) * cs, n)
+        lc[:r1 - r0] = localt[r0:r1]
+    stats = {}
+    pipelined_gather(compute, nch, cs, n, parts, 1, out2, None, stats)
+    assert torch.equal(out2, out), cs
+    assert stats["collective"] == "all_gather" and stats["bytes_sent_per_rank"] == nch * cs * (1 + wmax) * 8 * (world - 1)
+
+# 3. consumer form: sharded first Linear layer, reduce-scatter of the partial sums, all-gather of the finished rows
+rng = np.random.default_rng(5)
+H, d = 10, g["X"].shape[1]
+W = rng.standard_normal((H, 1 + S + d)); bvec = rng.standard_normal(H)
+pre = full @ W[:, :1 + S].T + g["X"] @ W[:, 1 + S:].T + bvec
+ref = np.where(pre >= 0, pre, 0.2 * pre)
+hm = 1 if rank == 0 else 0
+Eblk = torch.from_numpy(np.concatenate([full[:, :hm], full[:, 1 + ka:1 + kb]], axis=1))
+W1blk = torch.from_numpy(np.concatenate([W[:, :hm], W[:, 1 + ka:1 + kb]], axis=1))
+Xt, W2t, bt = torch.from_numpy(g["X"].astype(np.float64)), torch.from_numpy(W[:, 1 + S:]), torch.from_numpy(bvec)
+def finish(r0, r1, R):
+    R.addmm_(Xt[r0:r1], W2t.t()); R.add_(bt)
+    torch.nn.functional.leaky_relu(R, 0.2, inplace=True)
+for cs in (8 * world, 16 * world, 64 * world):
+    nch = -(-n // cs)
+    def partial(c, Pc):
+        r0, r1 = c * cs, min((c + 1) * cs, n)
+        Pc[:r1 - r0] = Eblk[r0:r1] @ W1blk.t()
+    stats = {}
+    Y = reduce_scatter_pipeline(partial, finish, nch, cs, n, H, torch.float64, torch.device("cpu"), None, "replicated", stats)
+    assert tuple(Y.shape) == (n, H)
+    e = float(np.abs(Y.numpy() - ref).max() / np.abs(ref).max())
+    assert e < 1e-13, e                                             # a sum over the ranks: summation order differs, nothing else
+    assert stats["collective"] == "reduce_scatter+all_gather"
+    R, row0 = reduce_scatter_pipeline(partial, finish, nch, cs, n, H, torch.float64, torch.device("cpu"), None, "sharded")
+    m = cs // world
+    for c in range(nch):
+        r0 = int(row0[c]); r1 = min(r0 + m, n)
+        assert r0 == c * cs + rank * m
+        if r1 > r0:
+            assert float(np.abs(R[c, :r1 - r0].numpy() - ref[r0:r1]).max() / np.abs(ref).max()) < 1e-13
 dist.barrier()
 if rank == 0:
     print("SHARD_OK")
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slice_sharding_allgather_gloo(world, tmp_path):
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_slice_sharding_collective_forms_gloo(world, tmp_path):
+    """dist.py's three ways of reassembling a slice-sharded layer (all-gather, pipelined all-gather, sharded consumer with
+    reduce-scatter), the kernels replaced by the oracle restricted to the rank's slices."""
     golden("tiny_graph")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
@@ -147,8 +197,17 @@ def test_slice_sharding_allgather_gloo(world, tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=180) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     assert "SHARD_OK" in outs[0][0]
+
+
+def test_chunk_plan():
+    from fsw_gnn_amd.dist import chunk_plan
+    from fsw_gnn_amd.graph import round_chunk_rows
+    assert round_chunk_rows(1) == 2048 and round_chunk_rows(2049) == 4096 and round_chunk_rows(5000, 3) == 6144
+    for n, world, want in ((1_000_000, 8, 4), (1_000_000, 2, 4), (3000, 4, 2), (10, 3, 5), (1_000_000, 8, 1)):
+        cs, nch = chunk_plan(n, world, want)
+        assert cs % 2048 == 0 and cs % world == 0 and nch * cs >= n and (nch - 1) * cs < n and nch <= want
 
 
 def test_coherence_minimisation_matches_reference():
