@@ -202,21 +202,22 @@ def collectives_alone(stats, n, H, width, world, reps, dev):
     (bytes a rank receives per second).  Un-overlapped: the step hides part of it under the kernels."""
     if not stats:
         return None
+    from fsw_gnn_amd import dist as D
     if stats.get("mode") == "consumer":
         rows = -(-n // world) * world
         P = torch.zeros((rows, H), dtype=torch.float32, device=dev)
         R = torch.empty((rows // world, H), dtype=torch.float32, device=dev)
 
         def fn():
-            dist.reduce_scatter_tensor(R, P)
+            D._reduce_scatter(R, P, None, False)
             if "all_gather" in stats.get("collective", ""):
-                dist.all_gather_into_tensor(P, R)
+                D._all_gather(P, R, None, False)
     else:
         loc = torch.zeros((n, width), dtype=torch.float32, device=dev)
         flat = torch.empty((world * n, width), dtype=torch.float32, device=dev)
 
         def fn():
-            dist.all_gather_into_tensor(flat, loc)
+            D._all_gather(flat, loc, None, False)
     ms = timed_ms(fn, reps, dev)
     t = torch.tensor([ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

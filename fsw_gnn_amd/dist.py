@@ -235,7 +235,8 @@ def sharded_embed_autograd(emb_mod, X, graph, out_scale=1.0, group=None, edge_fe
         raise NotImplementedError("fsw_gnn_amd: slice-parallel training needs at least one slice per rank")
     has_mass = 1 if emb_mod.encode_total_mass else 0
     parts = slice_partition(emb_mod.nSlices, world)
-    local = emb_mod.embed_autograd(X, graph, out_scale=out_scale, edge_feat=edge_feat, slice_range=parts[rank], group=group)
+    local = emb_mod.embed_autograd(X, graph, out_scale=out_scale, edge_feat=edge_feat, slice_range=parts[rank], group=group,
+                                   reduce_grads=True)
     return _AllGatherSlices.apply(local, parts, has_mass, group)
 
 

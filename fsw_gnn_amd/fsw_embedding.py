@@ -56,12 +56,12 @@ class _EmbedGraphFn(torch.autograd.Function):
 
     slice_range = (ka, kb): only slices ka..kb-1 (multi-GPU slice sharding, dist.py): the output is
     [mass column | slices ka..kb-1] and the parameter gradients are full-size tensors that are zero outside the block.
-    With `group` the block gradients of all ranks are summed by all_reduce inside backward, so that every rank ends with
+    With reduce_grads the block gradients of all ranks of `group` are summed by all_reduce inside backward, so that every rank ends with
     the gradients one GPU would compute (the mass column, replicated on every rank, is counted once).
     """
 
     @staticmethod
-    def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale, slice_range, group):
+    def forward(ctx, X, projVecs, freqs, bias, mass_scale, edge_feat, module, graph, out_scale, slice_range, group, reduce_grads):
         ka, kb = (0, module.nSlices) if slice_range is None else slice_range
         has_mass = 1 if module.encode_total_mass else 0
         with torch.no_grad():
@@ -72,7 +72,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             out = torch.empty((graph.num_rows, has_mass + kb - ka), dtype=X.dtype, device=X.device)
             module.embed_into(X, graph, out, out_scale=out_scale, prepared=prepared)
         ctx.module, ctx.graph, ctx.prepared, ctx.out_scale = module, graph, prepared, float(out_scale)
-        ctx.slice_range, ctx.group = (ka, kb), group
+        ctx.slice_range, ctx.group, ctx.reduce_grads = (ka, kb), group, bool(reduce_grads)
         ctx.num_edge_rows = 0 if edge_feat is None else edge_feat.shape[0]
         ctx.save_for_backward(X, projVecs, freqs)
         return out
@@ -84,7 +84,7 @@ class _EmbedGraphFn(torch.autograd.Function):
         X, Vfull, freqs_full = ctx.saved_tensors
         ka, kb = ctx.slice_range
         group = ctx.group
-        sharded = group is not None
+        sharded = ctx.reduce_grads        # group may be None = the default process group
         L = _lib.lib()
         S, has_mass = kb - ka, (1 if module.encode_total_mass else 0)
         V = Vfull.detach()[ka:kb]
@@ -173,7 +173,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             for t in (gX, gV, gfreqs, gbias, gEf):
                 if t is not None:
                     dist.all_reduce(t, group=group)
-        return gX, gV, gfreqs, gbias, gscale, gEf, None, None, None, None, None
+        return gX, gV, gfreqs, gbias, gscale, gEf, None, None, None, None, None, None
 
 
 def dist_rank(group):
@@ -479,21 +479,22 @@ class FSW_embedding(nn.Module):
             self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
         return out.reshape(out_shape + (self.d_out,))
 
-    def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None, slice_range=None, group=None):
+    def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None, slice_range=None, group=None, reduce_grads=False):
         """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn.  edge_feat: the per-input-edge
         feature tensor the graph was coalesced from (its gradient is routed back through graph.slot_of_edge).
         slice_range / group: this rank's block of slices under slice sharding (dist.py)."""
         bias = self.bias if self.enable_bias else None
         scale = self.total_mass_encoding_scale if self.encode_total_mass else None
         if (not self.encode_total_mass) or self.total_mass_encoding_method == 'plain':
-            return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale, slice_range, group)
+            return _EmbedGraphFn.apply(X, self.projVecs, self.freqs, bias, scale, edge_feat, self, graph, out_scale, slice_range, group,
+                                       reduce_grads)
         if slice_range is not None:
             raise NotImplementedError("slice sharding supports total_mass_encoding_method='plain' only")
         # 'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144): the 'plain' embedding without bias from the
         # kernels, then the same epilogue as embed_into(), out of place so that autograd differentiates it
         self._force_plain = True
         try:
-            P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale, None, None)
+            P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale, None, None, False)
         finally:
             self._force_plain = False
         tm = P[:, 0:1] / out_scale
