@@ -271,13 +271,18 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
                                                             float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
                                                             float out_scale, int has_mass, int mass_fn, float mass_scale,
                                                             const float* __restrict__ efeat, const float* __restrict__ Ve,
-                                                            int64_t ldve, int d_edge, char* __restrict__ scratch, int64_t wave_bytes) {
+                                                            int64_t ldve, int d_edge, char* __restrict__ scratch, int64_t wave_bytes,
+                                                            int bin_lo) {
   constexpr int CAP = M * kWave;
   const int lane = lane_id();
-  const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
+  // lines are numbered (row, slice) with the slice fastest; the workgroups of one XCD (blockIdx.x % 8 under round-robin
+  // dispatch) take consecutive lines when the grid is a multiple of 8, so that the slices sharing a sector of an Xp row
+  // are read through the same L2
+  const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  const int gw = blk * 4 + wave_id(), nwaves = gridDim.x * 4;
   float* sk = reinterpret_cast<float*>(scratch + (int64_t)gw * wave_bytes);
   float* sw = sk + (wave_bytes >> 3);                   // second half of the wave's region (weighted only)
-  const int pbeg = bin_start[FSW_BIN_GLOBAL], pend = bin_start[FSW_BIN_GLOBAL + 1];
+  const int pbeg = bin_start[bin_lo], pend = bin_start[FSW_BIN_GLOBAL + 1];
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
     const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
@@ -305,7 +310,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
       WaveLine<M, WEIGHTED> ln;
 #pragma unroll
       for (int j = 0; j < M; ++j) {
-        const int t = c0 + lane * M + j;
+        const int t = c0 + j * kWave + lane;              // striped: lane-contiguous col / w reads (the chunk is sorted next)
         float key = __builtin_inff(), wt = 0.f;
         if (t < D) {
           key = (FSW_WSG_ABL & 1) ? (float)((t * 2654435761u) >> 8) : Xp[(int64_t)col[start + t] * ldp + k];
@@ -412,22 +417,31 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
   }
 }
 
+// unit weights (tau <= 1): only the rows above FSW_HUB_MAX_DEG come here (embed_hub.hip takes the hub bins); general
+// weights: every row above FSW_LDS_MAX_DEG
+int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
+
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
   const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
   FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
+  if (unit_fast && a.max_degree <= FSW_HUB_MAX_DEG) return 0;
+  FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
   const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
   const int64_t wave_bytes = Dp * 8;
   int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
-  nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 4) * 4) & ~(int64_t)3;
+  nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 32) * 32);
+  nwaves = nwaves >= 32 ? (nwaves & ~(int64_t)31) : (nwaves & ~(int64_t)3);   // whole workgroups; a multiple of 8 of them when possible
   FSW_REQUIRE(nwaves >= 4, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
   char* scratch = reinterpret_cast<char*>(a.scratch);
   if (unit_fast)
     k_embed_wsort_global<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes);
+        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
+        FSW_BIN_GLOBAL);
   else
     k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes);
+        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
+        FSW_BIN_HUB0);
   FSW_LAUNCH_CHECK();
   return 0;
 }
@@ -453,10 +467,8 @@ int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
   if (rows_upper <= 0) return 0;
   const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
   int rc;
-  if (unit_fast) {   // a wave holds 64 M keys
-    if ((rc = launch_wsort<8, false>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, stream))) return rc;
-    if ((rc = launch_wsort<16, false>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;
-    if ((rc = launch_wsort<32, false>(a, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, rows_upper, stream))) return rc;
+  if (unit_fast) {   // one wavefront per line straight from Xp, no LDS staging (embed_hub.hip)
+    return launch_embed_ws_unit(a, rows_upper, stream);
   } else {           // D + 1 elements with the pad element: one size up; the mid bins above FSW_MID_MAX_DEG_WEIGHTED come here too
     constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
     int bin_lo = FSW_BIN_MID0;

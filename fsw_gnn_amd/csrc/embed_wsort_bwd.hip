@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
   const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
   unsigned long long* se = reinterpret_cast<unsigned long long*>(scratch + (int64_t)gw * wave_bytes);   // packed (key, index) words
   float* sc = reinterpret_cast<float*>(se + wave_bytes / 12);                                           // contributions, element order
-  const int pbeg = bin_start[FSW_BIN_GLOBAL], pend = bin_start[FSW_BIN_GLOBAL + 1];
+  const int pbeg = bin_start[FSW_BIN_HUB0], pend = bin_start[FSW_BIN_GLOBAL + 1];   // every row above FSW_LDS_MAX_DEG
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
     const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);

@@ -39,7 +39,8 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 
 __host__ __device__ inline int degree_bin(int deg) {
   if (deg <= FSW_REG_MAX_DEG) return deg;
-  if (deg > FSW_LDS_MAX_DEG) return FSW_BIN_GLOBAL;
+  if (deg > FSW_HUB_MAX_DEG) return FSW_BIN_GLOBAL;
+  if (deg > FSW_LDS_MAX_DEG) return FSW_BIN_HUB0 + (deg > 4096) + (deg > 8192) + (deg > 16384);
   if (deg > FSW_MID_MAX_DEG) return FSW_BIN_LDS0 + (deg > 512) + (deg > 1024);
   constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
   int i = 0;
@@ -55,5 +56,6 @@ __host__ __device__ inline uint32_t pow2ceil(uint32_t v) {
 }
 
 static_assert(FSW_NUM_LDS_BINS == 3 && FSW_MID_MAX_DEG == 256 && FSW_LDS_MAX_DEG == 2048, "degree_bin assumes LDS bins 512 / 1024 / 2048");
+static_assert(FSW_NUM_HUB_BINS == 4 && FSW_HUB_MAX_DEG == 32768, "degree_bin assumes hub bins 4096 / 8192 / 16384 / 32768");
 
 }  // namespace fsw

@@ -388,14 +388,16 @@ __global__ void __launch_bounds__(kMaxRowChunks) k_bin_offsets(const int32_t* __
       bs[b] = acc;
       bin_cursor[c * FSW_NUM_BINS + b] = acc;
       if (b >= 1 && b <= FSW_REG_MAX_DEG) reg += cnt[b];
-      if (b >= FSW_BIN_MID0 && b < FSW_BIN_GLOBAL) mid += cnt[b];
+      if (b >= FSW_BIN_MID0 && b < FSW_BIN_HUB0) mid += cnt[b];
       acc += cnt[b];
     }
     bs[FSW_NUM_BINS] = acc;
     if (cnt[0]) atomicAdd(&stats[FSW_STAT_NUM_ZERO_DEG], cnt[0]);
     if (reg) atomicAdd(&stats[FSW_STAT_NUM_REG], reg);
     if (mid) atomicAdd(&stats[FSW_STAT_NUM_LDS], mid);
-    if (cnt[FSW_BIN_GLOBAL]) atomicAdd(&stats[FSW_STAT_NUM_GLOBAL], cnt[FSW_BIN_GLOBAL]);
+    int glob = 0;
+    for (int b = FSW_BIN_HUB0; b <= FSW_BIN_GLOBAL; ++b) glob += cnt[b];
+    if (glob) atomicAdd(&stats[FSW_STAT_NUM_GLOBAL], glob);
   }
 }
 

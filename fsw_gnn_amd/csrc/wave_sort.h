@@ -27,11 +27,15 @@ __device__ __forceinline__ float xor_lane(float v) {
   else if constexpr (MASK == 7) return __int_as_float(dpp(x, integral_constant<int, 0x141>{}));
   else if constexpr (MASK == 15) return __int_as_float(dpp(x, integral_constant<int, 0x140>{}));
   else if constexpr (MASK == 4) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x141>{}), integral_constant<int, 0x1B>{}));
-  else if constexpr (MASK == 8) return __int_as_float(dpp(dpp(x, integral_constant<int, 0x140>{}), integral_constant<int, 0x141>{}));
+  else if constexpr (MASK == 8) return __int_as_float(dpp(x, integral_constant<int, 0x128>{}));   // row_ror:8 = xor 8 inside a row of 16
   else if constexpr (MASK == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401F));
   else if constexpr (MASK == 31) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x7C1F));
   else return __shfl_xor(v, MASK);
 }
+
+// min(a, b) where lim == -inf, max(a, b) where lim == +inf: ONE v_med3_f32 instead of v_min + v_max + v_cndmask when the
+// side of the pair is a per-lane property (keys are never NaN: the inputs are validated)
+__device__ __forceinline__ float minmax_by_limit(float a, float b, float lim) { return __builtin_amdgcn_fmed3f(a, b, lim); }
 
 // keys (and weights) of one line across the wave, blocked layout; ascending over element index l*M + j afterwards
 // TIEBREAK: the payload is the element index and equal keys are ordered by it (= a stable sort by key, the order the
@@ -45,6 +49,7 @@ struct WaveLine {
   template <int JREV, int MASK>
   __device__ __forceinline__ void exchange(bool lower) {
     float ok[M], ow[WEIGHTED ? M : 1];
+    const float lim = lower ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       ok[j] = xor_lane<MASK>(k[JREV ? M - 1 - j : j]);
@@ -61,7 +66,7 @@ struct WaveLine {
         k[j] = take ? ok[j] : k[j];
         w[j] = take ? ow[j] : w[j];
       } else {
-        k[j] = lower ? fminf(k[j], ok[j]) : fmaxf(k[j], ok[j]);
+        k[j] = minmax_by_limit(k[j], ok[j], lim);
       }
     }
   }

@@ -43,19 +43,26 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
  *   bin FSW_BIN_LDS0 + i             : 256 << i < degree <= 512 << i, i < FSW_NUM_LDS_BINS (wave-sort path: the
  *                                      neighbourhood is transposed through LDS, every wavefront sorts one slice's
  *                                      line held across its lanes' registers)
- *   bin FSW_BIN_GLOBAL               : degree > FSW_LDS_MAX_DEG (global-scratch bitonic path)
+ *   bin FSW_BIN_HUB0 + i             : 2048 << i < degree <= 4096 << i, i < FSW_NUM_HUB_BINS (hub path: a workgroup of 2 << i
+ *                                      wavefronts holds ONE slice's line in its registers, 2048 keys per wavefront; the merge
+ *                                      levels above one wavefront exchange registers through LDS)
+ *   bin FSW_BIN_GLOBAL               : degree > FSW_HUB_MAX_DEG (global-scratch bitonic path, any degree)
  * General (non-unit) weights carry a weight next to every key, so their per-lane register path ends at
- * FSW_MID_MAX_DEG_WEIGHTED and the bins above it run on the wave-sort path.                            */
+ * FSW_MID_MAX_DEG_WEIGHTED and the bins above it run on the wave-sort path; weighted rows above FSW_LDS_MAX_DEG all take
+ * the global-scratch path.                                                                                            */
 #define FSW_REG_MAX_DEG 32
 #define FSW_NUM_MID_BINS 9
 #define FSW_MID_SIZES {40, 48, 64, 80, 96, 128, 160, 192, 256}
 #define FSW_MID_MAX_DEG 256
 #define FSW_MID_MAX_DEG_WEIGHTED 128
 #define FSW_LDS_MAX_DEG 2048
+#define FSW_HUB_MAX_DEG 32768
 #define FSW_BIN_MID0 (FSW_REG_MAX_DEG + 1)
 #define FSW_NUM_LDS_BINS 3
 #define FSW_BIN_LDS0 (FSW_BIN_MID0 + FSW_NUM_MID_BINS)
-#define FSW_BIN_GLOBAL (FSW_BIN_LDS0 + FSW_NUM_LDS_BINS)
+#define FSW_NUM_HUB_BINS 4
+#define FSW_BIN_HUB0 (FSW_BIN_LDS0 + FSW_NUM_LDS_BINS)
+#define FSW_BIN_GLOBAL (FSW_BIN_HUB0 + FSW_NUM_HUB_BINS)
 #define FSW_NUM_BINS (FSW_BIN_GLOBAL + 1)
 
 /* stats[] words written by fsw_graph_build / fsw_project_f32 (device int32[FSW_NUM_STATS]) */
@@ -64,7 +71,7 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
 #define FSW_STAT_NUM_ZERO_DEG 2
 #define FSW_STAT_NUM_REG 3      /* rows with 1 <= degree <= FSW_REG_MAX_DEG */
 #define FSW_STAT_NUM_LDS 4      /* rows with FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (mid bins + LDS bin) */
-#define FSW_STAT_NUM_GLOBAL 5
+#define FSW_STAT_NUM_GLOBAL 5   /* rows with degree > FSW_LDS_MAX_DEG (hub bins + global bin) */
 #define FSW_STAT_NNZ 6          /* fsw_graph_build_coalesced: number of CSR entries after coalescing */
 #define FSW_STAT_USER 7         /* never written by the library after the build zeroes it: the Python side parks the bits of
                                    the total-mass scale here so that ONE device->host copy per forward fetches everything */

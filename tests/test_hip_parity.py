@@ -91,7 +91,7 @@ def test_graph_build_matches_oracle_adjacency(dev):
     assert sorted(perm) == list(range(64))
     for b in range(len(bins) - 1):
         for r in perm[bins[b]:bins[b + 1]]:
-            assert min(deg_ref[r], 33) == b or (deg_ref[r] > 2048 and b == 34)
+            assert min(deg_ref[r], 33) == b
     assert gr.max_degree == deg_ref.max() and gr.stats()[2] == (deg_ref == 0).sum()
     # out-of-range endpoints are flagged, not dereferenced
     bad = ei.copy()
@@ -279,7 +279,7 @@ def test_mid_degree_rows_every_padded_network_size(dev):
         assert st[_lib.STAT_NUM_LDS] == nrows and st[_lib.STAT_NUM_REG] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0
         bs = graph.bin_start.cpu().numpy()
         assert bs[_lib.NUM_BINS] == nrows and bs[_lib.REG_MAX_DEG + 1] == 0
-        assert np.diff(bs)[_lib.REG_MAX_DEG + 1:].tolist() == [3, 2, 2, 2, 2, 3, 2, 2, 3, 2, 0, 0, 0]   # rows per mid bin, three LDS bins, global
+        assert np.diff(bs)[_lib.REG_MAX_DEG + 1:].tolist() == [3, 2, 2, 2, 2, 3, 2, 2, 3, 2, 0, 0, 0, 0, 0, 0, 0]   # rows per mid bin, three LDS bins, four hub bins, global
         ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if weights is None else weights.astype(np.float64), V, fr,
                                       bias=bias, encode_total_mass=True, total_mass_encoding_scale=0.7)
         assert relerr(out.cpu().numpy(), ref) < TOL
@@ -310,11 +310,45 @@ def test_wave_sort_rows_every_size_class(dev):
             out = torch.empty((nrows, S + 1), device=dev)
             E.embed_into(t(X, dev), graph, out)
         bs = np.diff(graph.bin_start.cpu().numpy())
-        assert bs[-4:].tolist() == [2, 3, 2, 0] and bs[:-4].sum() == 0
+        assert bs[-8:].tolist() == [2, 3, 2, 0, 0, 0, 0, 0] and bs[:-8].sum() == 0
         ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if weights is None else weights.astype(np.float64), V, fr,
                                       encode_total_mass=True)
         assert relerr(out.cpu().numpy(), ref) < TOL
         assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_hub_rows_every_size_class(dev):
+    """Rows of 2049..33000 neighbours at both ends of the four hub classes (csrc/embed_hub.hip: a workgroup of 2 / 4 / 8 / 16
+    wavefronts holds one slice's line, 2048 keys per wavefront, merge levels above a wavefront through LDS) and one row above
+    them (global-scratch path); unit weights take the hub kernels, general weights the scratch path; a zero frequency;
+    several rows per class so that the XCD-interleaved block order is exercised."""
+    from fsw_gnn_amd import build_csr, _lib
+    rng = np.random.default_rng(29)
+    sizes = [2049, 4096, 4097, 8192, 8193, 16384, 16385, 32768, 33000, 3000, 5000, 6000, 7000, 4100, 9000, 9001, 9002, 2500]
+    nrows, n, d, S = len(sizes), 40_000, 6, 11
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=87)
+    fr = cases.random_freqs(S, seed=88)
+    fr[2] = 0.0
+    rec = np.repeat(np.arange(nrows), sizes).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
+    w = (rng.random(rec.size) + 0.1).astype(np.float32)
+    w[rec == 0] *= 0.3 / w[rec == 0].sum()
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    for weights in (None, w):
+        E = make_embedding(dev, V, fr, enable_bias=False, encode_total_mass=True)
+        with torch.no_grad():
+            graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), nrows, n)
+            out = torch.empty((nrows, S + 1), device=dev)
+            E.embed_into(t(X, dev), graph, out)
+        bs = np.diff(graph.bin_start.cpu().numpy())
+        assert bs[-5:].tolist() == [4, 6, 5, 2, 1] and bs[:-5].sum() == 0 and graph.stats()[_lib.STAT_NUM_GLOBAL] == nrows
+        ref = C.embed(X, rowptr, snd, weights, V, fr)
+        got = out.cpu().numpy()
+        assert relerr(got[:, 1:], ref) < TOL
+        assert np.abs(got[:, 1:] - ref).max() < 2e-5 * np.abs(ref).max()
+        mass = np.array(sizes, dtype=np.float64) if weights is None else np.bincount(rec, weights=weights.astype(np.float64))
+        assert np.allclose(got[:, 0], mass, rtol=1e-5)
 
 
 def test_mid_degree_rows_backward(dev):

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     abi = int(re.search(r"#define FSW_ABI_VERSION (\d+)", header).group(1))
     assert L.fsw_abi_version() == abi == _lib.FSW_ABI_VERSION and L.fsw_arch() == b"gfx950"
     sizes = tuple(int(v) for v in re.search(r"#define FSW_MID_SIZES \{([^}]*)\}", header).group(1).split(","))
-    assert sizes == _lib.MID_SIZES and _lib.NUM_BINS == _lib.REG_MAX_DEG + 1 + len(sizes) + _lib.NUM_LDS_BINS + 1
+    assert sizes == _lib.MID_SIZES and _lib.NUM_BINS == _lib.REG_MAX_DEG + 1 + len(sizes) + _lib.NUM_LDS_BINS + _lib.NUM_HUB_BINS + 1
     # size helpers are pure host functions
     assert L.fsw_unit_table_rows(32) == 528
     assert L.fsw_graph_workspace_bytes(1000, 10_000) >= 24 * 10_000      # two (key, value) ping-pong buffers
