@@ -8,6 +8,7 @@ int launch_embed_reg(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
 int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper, hipStream_t stream);
 int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
 int launch_embed_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
+int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
 size_t embed_global_scratch_bytes(int64_t max_degree);
 }  // namespace fsw
@@ -52,8 +53,12 @@ extern "C" int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream_) {
   if (nlds > 0 && (rc = launch_embed_mid(a, unit_fast, nlds, stream))) return rc;
   if (nlds > 0 && (rc = launch_embed_lds(a, nlds, stream))) return rc;
   if (nglob > 0) {   // rows above FSW_LDS_MAX_DEG: hub kernels (unit weights, up to FSW_HUB_MAX_DEG), scratch-line kernel for the rest
-    if (unit_fast && (rc = launch_embed_hub(a, nglob, stream))) return rc;
-    if ((rc = launch_embed_global(a, nglob, stream))) return rc;
+    if (unit_fast) {
+      if ((rc = launch_embed_hub(a, nglob, stream))) return rc;
+      if ((rc = launch_embed_giant(a, nglob, stream))) return rc;
+    } else if ((rc = launch_embed_global(a, nglob, stream))) {
+      return rc;
+    }
   }
   return 0;
 }

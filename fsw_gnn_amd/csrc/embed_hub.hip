@@ -35,17 +35,109 @@ __device__ __forceinline__ float mass_encode_h(float m, int fn) {
   return m;
 }
 
+// ---- building blocks shared by the kernels below ---------------------------------------------------------------------
+// register exchange between the wavefronts of a workgroup through xbuf [NW][CAP]: this wavefront keeps, element by
+// element, the smaller (lower) or larger key of (its own, wavefront `partner`'s -- same element, or mirrored)
+template <int M>
+__device__ __forceinline__ void wave_exchange(WaveLine<M, false>& ln, float* __restrict__ xbuf, int w, int lane, int partner,
+                                              bool mirrored, bool lower) {
+  constexpr int CAP = M * kWave;
+  // one base register per side and immediate offsets j * 256 B: the asm statements keep the compiler from folding the lane
+  // term into 32 separate per-element addresses (v_bitop3 of lane ^ constant), which it then hoists out of loops and spills
+  float* mine = xbuf + w * CAP + lane;
+  asm volatile("" : "+v"(mine));
+#pragma unroll
+  for (int j = 0; j < M; ++j) mine[j * kWave] = ln.k[j];
+  __syncthreads();
+  const float* theirs = xbuf + partner * CAP + (mirrored ? kWave - 1 - lane : lane);
+  asm volatile("" : "+v"(theirs));
+  const float lim = lower ? -__builtin_inff() : __builtin_inff();   // wave-uniform: min below the partner, max above it
+#pragma unroll
+  for (int j = 0; j < M; ++j) ln.k[j] = minmax_by_limit(ln.k[j], theirs[(mirrored ? M - 1 - j : j) * kWave], lim);
+  __syncthreads();   // everybody has read: the buffer may be overwritten by the next exchange
+}
+
+// NW sorted chunks (one per wavefront, after WaveLine::sort) -> the workgroup's NW * CAP keys sorted; element (lane, j) of
+// wavefront w then has rank w * CAP + lane * M + j
+template <int NW, int M>
+__device__ __forceinline__ void workgroup_merge_levels(WaveLine<M, false>& ln, float* __restrict__ xbuf, int w, int lane) {
+#pragma unroll
+  for (int size = 2; size <= ((FSW_HUB_ABL & 4) ? 0 : NW); size <<= 1) {
+    wave_exchange<M>(ln, xbuf, w, lane, w ^ (size - 1), true, (w & (size >> 1)) == 0);        // element E against E ^ (size * CAP - 1)
+    for (int st = size >> 2; st >= 1; st >>= 1) wave_exchange<M>(ln, xbuf, w, lane, w ^ st, false, (w & st) == 0);
+    ln.merge_chunk();
+  }
+}
+
+// the workgroup's NW * CAP keys form a bitonic sequence whose halves were separated elsewhere: finish the merge
+template <int NW, int M>
+__device__ __forceinline__ void workgroup_merge_block(WaveLine<M, false>& ln, float* __restrict__ xbuf, int w, int lane) {
+#pragma unroll
+  for (int st = NW >> 1; st >= 1; st >>= 1) wave_exchange<M>(ln, xbuf, w, lane, w ^ st, false, (w & st) == 0);
+  ln.merge_chunk();
+}
+
+// unit-weight readout of the lane's M keys of ranks r0 .. r0 + M - 1 in a neighbourhood of D: coefficients
+// (1 + xi) [sin(2 pi xi (r + 1) / D) - sin(2 pi xi r / D)] / (pi xi) (reference fsw_embedding.py:1047-1075, 1109 with
+// weights 1 / D) by a float64 rotation started at the lane's first rank.  Returns the lane's partial sum.
+template <int M>
+__device__ __forceinline__ float unit_readout(const WaveLine<M, false>& ln, int r0, int D, float xif) {
+  const double xi = (double)xif;
+  const double inv = 1.0 / (double)D;
+  float acc = 0.f;
+  if (xif < 1e-30f) {                       // xi == 0: Delta_t = 2 w_t
+#pragma unroll
+    for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
+    return acc * 2.f * (float)inv;
+  }
+  const double step = xi * inv;             // revolutions per rank
+  double sd, cd, s, c;
+  sincospi(2.0 * (step - rint(step)), &sd, &cd);
+  const double x0 = step * (double)r0;
+  sincospi(2.0 * (x0 - rint(x0)), &s, &c);
+  const double scale = (1.0 + xi) / (kPiH * xi);
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
+    acc += (r0 + j < D) ? (float)(scale * (sn - s)) * ln.k[j] : 0.f;
+    s = sn;
+    c = cn;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float wave_sum_h(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// gather elements t0 + j * 64 + lane (j < M; striped: lane-contiguous col reads -- the chunk is sorted next) of slice k
+template <int M>
+__device__ __forceinline__ void gather_chunk(WaveLine<M, false>& ln, const int32_t* __restrict__ colrow, int t0, int D,
+                                             const float* __restrict__ Xp, int64_t ldp, int k, int lane) {
+  int c[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int t = t0 + j * kWave + lane;
+    c[j] = t < D ? colrow[t] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j)
+    ln.k[j] = c[j] >= 0 ? ((FSW_HUB_ABL & 1) ? (float)((c[j] * 2654435761u) >> 8) : Xp[(int64_t)c[j] * ldp + k]) : __builtin_inff();
+}
+
 // NW wavefronts per line, M keys per lane; NW == 1: the workgroup is four independent wavefronts on four lines (adjacent
 // slices of one row) and never synchronises -- the wave-sort classes 257..2048 (M = 8 / 16 / 32) run this way
 template <int NW, int M>
-__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave) k_embed_hub(
+__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
     int has_mass, int mass_fn, float mass_scale) {
   constexpr int CAP = M * kWave;
   constexpr int LPB = NW == 1 ? 4 : 1;   // lines per block
-  __shared__ float xbuf[NW > 1 ? NW : 1][NW > 1 ? CAP : 1];   // exchange buffer: element (lane, j) of wavefront w at xbuf[w][j * 64 + lane]
+  __shared__ float xbuf[NW > 1 ? NW * CAP : 1];   // exchange buffer: element (lane, j) of wavefront w at xbuf[w * CAP + j * 64 + lane]
   __shared__ float red[NW];
   const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
   const int lane = lane_id();
@@ -62,82 +154,13 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave) k_embed_hub(
   const int start = rowptr[node];
   const int D = rowptr[node + 1] - start;
 
-  // 1. gather this wavefront's chunk (striped: element j * 64 + lane of the chunk) and sort it
   WaveLine<M, false> ln;
-  {
-    int c[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const int t = w * CAP + j * kWave + lane;
-      c[j] = t < D ? col[start + t] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < M; ++j)
-      ln.k[j] = c[j] >= 0 ? ((FSW_HUB_ABL & 1) ? (float)((c[j] * 2654435761u) >> 8) : Xp[(int64_t)c[j] * ldp + k]) : __builtin_inff();
-  }
+  gather_chunk<M>(ln, col + start, w * CAP, D, Xp, ldp, k, lane);
   if (!(FSW_HUB_ABL & 2)) ln.sort();
-
-  // 2. merge levels above one wavefront: `size` sorted chunks -> one sorted run
+  if constexpr (NW > 1) workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
+  float tot = wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, freqs[k]));
   if constexpr (NW > 1) {
-    auto exchange = [&](int partner, bool mirrored, bool lower) {
-      float* mine = xbuf[w];
-#pragma unroll
-      for (int j = 0; j < M; ++j) mine[j * kWave + lane] = ln.k[j];
-      __syncthreads();
-      const float* theirs = xbuf[partner];
-      float o[M];
-#pragma unroll
-      for (int j = 0; j < M; ++j) o[j] = mirrored ? theirs[(M - 1 - j) * kWave + (kWave - 1 - lane)] : theirs[j * kWave + lane];
-      if (lower) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) ln.k[j] = fminf(ln.k[j], o[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < M; ++j) ln.k[j] = fmaxf(ln.k[j], o[j]);
-      }
-      __syncthreads();   // everybody has read: the buffer may be overwritten by the next exchange
-    };
-#pragma unroll
-    for (int size = 2; size <= ((FSW_HUB_ABL & 4) ? 0 : NW); size <<= 1) {
-      exchange(w ^ (size - 1), true, (w & (size >> 1)) == 0);        // element E against E ^ (size * CAP - 1)
-      for (int st = size >> 2; st >= 1; st >>= 1) exchange(w ^ st, false, (w & st) == 0);
-      ln.merge_chunk();
-    }
-  }
-
-  // 3. readout: element (lane, j) of wavefront w has rank w * CAP + lane * M + j; coefficients
-  //    (1 + xi) [sin(2 pi xi (r + 1) / D) - sin(2 pi xi r / D)] / (pi xi) (reference fsw_embedding.py:1047-1075, 1109 with
-  //    weights 1 / D) by a float64 rotation started at the lane's first rank
-  const float xif = freqs[k];
-  const double xi = (double)xif;
-  const bool lin = xif < 1e-30f;            // xi == 0: Delta_t = 2 w_t
-  const double inv = 1.0 / (double)D;
-  const int r0 = w * CAP + lane * M;
-  float acc = 0.f;
-  if (lin) {
-#pragma unroll
-    for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
-    acc *= 2.f * (float)inv;
-  } else {
-    const double step = xi * inv;           // revolutions per rank
-    double sd, cd, s, c;
-    sincospi(2.0 * (step - rint(step)), &sd, &cd);
-    const double x0 = step * (double)r0;
-    sincospi(2.0 * (x0 - rint(x0)), &s, &c);
-    const double scale = (1.0 + xi) / (kPiH * xi);
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
-      acc += (r0 + j < D) ? (float)(scale * (sn - s)) * ln.k[j] : 0.f;
-      s = sn;
-      c = cn;
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  float tot = acc;
-  if constexpr (NW > 1) {
-    if (lane == 0) red[w] = acc;
+    if (lane == 0) red[w] = tot;
     __syncthreads();
     tot = 0.f;
 #pragma unroll
@@ -148,6 +171,149 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave) k_embed_hub(
     orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
     if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
   }
+}
+
+// ---- rows above FSW_HUB_MAX_DEG, unit weights: blocks of 16384 keys sorted in the registers of an 8-wavefront workgroup --
+// A line (row, slice) of any length is cut into blocks of kGiantBlk = 8 * 2048 keys (8 wavefronts: 16 would leave 128 registers per lane and spill).  Every block is gathered and sorted
+// like a hub row and parked in the workgroup's scratch line (global memory, 4 bytes per key); the bitonic merge levels
+// above one block are element-wise min/max sweeps over pairs of blocks (coalesced, by all 512 threads) followed by the
+// in-workgroup tail of the level (workgroup_merge_block) on every block, back in registers; the last level feeds the readout
+// instead of going back to memory.  Blocks past the end of the row hold only +inf and are never touched: a pair with such a
+// block on its upper side is a no-op (the scratch-line kernel of embed_wsort.hip, which this replaces for unit weights,
+// swept every level at the granularity of one wavefront's 2048 keys: 28 sweeps for a 150 000-neighbour hub against 10 here).
+#ifndef FSW_GIANT_NW
+#define FSW_GIANT_NW 16
+#endif
+constexpr int kGiantNW = FSW_GIANT_NW;
+constexpr int kGiantBlk = kGiantNW * kHubM * kWave;   // 16384
+
+__global__ void __launch_bounds__(kGiantNW* kWave, 4) k_embed_giant(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const int32_t* __restrict__ perm,
+                                                                const int32_t* __restrict__ bin_start, const float* __restrict__ Xp,
+                                                                int64_t ldp, int S, const float* __restrict__ freqs,
+                                                                float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
+                                                                float out_scale, int has_mass, int mass_fn, float mass_scale,
+                                                                float* __restrict__ scratch, int64_t line_floats) {
+  constexpr int NW = kGiantNW, M = kHubM, CAP = M * kWave, BLK = kGiantBlk, NT = NW * kWave;
+  __shared__ float xbuf[NW * CAP];
+  __shared__ float red[NW];
+  const int pbeg = bin_start[FSW_BIN_GLOBAL], nrows = bin_start[FSW_BIN_GLOBAL + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  // the workgroups of one XCD take consecutive lines (slices of the same row) when the grid is a multiple of 8
+  const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  float* sl = scratch + (int64_t)blk * line_floats;
+  const int64_t nlines = (int64_t)nrows * S;
+  // order within the workgroup: every wavefront's scratch stores performed, then a barrier.  Workgroup scope is enough: the
+  // wavefronts of a workgroup share their CU's L1, which the CU's own stores write through (an agent-scope fence would write
+  // back the whole XCD's L2 at every one of the ~10 synchronisation points of a line: measured 3x the kernel time)
+  auto sync_scratch = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+  };
+  for (int64_t line = blk; line < nlines; line += gridDim.x) {
+    const int p = pbeg + (int)(line / S), k = (int)(line % S);
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int nb = (D + BLK - 1) / BLK;                   // blocks that hold keys
+    const int nbp = (int)pow2ceil((uint32_t)nb);
+    const float xif = freqs[k];
+    WaveLine<M, false> ln;
+    // A. blocks: gather, sort in the workgroup's registers, park in the scratch line
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+      gather_chunk<M>(ln, col + start, b * BLK + w * CAP, D, Xp, ldp, k, lane);
+      ln.sort();
+      workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
+      float* dst = sl + (int64_t)b * BLK + w * CAP + lane * M;
+#pragma unroll
+      for (int j = 0; j < M; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(ln.k[j], ln.k[j + 1], ln.k[j + 2], ln.k[j + 3]);
+    }
+    sync_scratch();
+    // B. merge levels above one block
+    float acc = 0.f;
+#pragma unroll 1
+    for (int size = 2; size <= nbp; size <<= 1) {
+      // element-wise exchanges between blocks: the flip (b against b ^ (size - 1), mirrored), then strides size / 4 .. 1
+      auto sweep = [&](bool flip, int st) {
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+          const int b2 = flip ? (b ^ (size - 1)) : (b ^ st);
+          if (b2 <= b || b2 >= nb) continue;              // each pair once, from its lower block; all-+inf partners: no-op
+          float* lo = sl + (int64_t)b * BLK;
+          float* hi = sl + (int64_t)b2 * BLK;
+#pragma unroll 2
+          for (int e = threadIdx.x * 4; e < BLK; e += NT * 4) {
+            const float4 x = *reinterpret_cast<const float4*>(lo + e);
+            float4 y;
+            if (flip) {                                    // lo[e] against hi[BLK - 1 - e]
+              const float4 t = *reinterpret_cast<const float4*>(hi + (BLK - 4 - e));
+              y = make_float4(t.w, t.z, t.y, t.x);
+            } else {
+              y = *reinterpret_cast<const float4*>(hi + e);
+            }
+            const float4 mn = make_float4(fminf(x.x, y.x), fminf(x.y, y.y), fminf(x.z, y.z), fminf(x.w, y.w));
+            const float4 mx = make_float4(fmaxf(x.x, y.x), fmaxf(x.y, y.y), fmaxf(x.z, y.z), fmaxf(x.w, y.w));
+            *reinterpret_cast<float4*>(lo + e) = mn;
+            if (flip) *reinterpret_cast<float4*>(hi + (BLK - 4 - e)) = make_float4(mx.w, mx.z, mx.y, mx.x);
+            else *reinterpret_cast<float4*>(hi + e) = mx;
+          }
+        }
+        sync_scratch();
+      };
+      sweep(true, 0);
+      for (int st = size >> 2; st >= 1; st >>= 1) sweep(false, st);
+      const bool last = size == nbp;
+#pragma unroll 1
+      for (int b = 0; b < nb; ++b) {
+        const float* src = sl + (int64_t)b * BLK + w * CAP + lane * M;
+#pragma unroll
+        for (int j = 0; j < M; j += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + j);
+          ln.k[j] = v.x; ln.k[j + 1] = v.y; ln.k[j + 2] = v.z; ln.k[j + 3] = v.w;
+        }
+        workgroup_merge_block<NW, M>(ln, xbuf, w, lane);
+        if (last) {
+          acc += unit_readout<M>(ln, b * BLK + w * CAP + lane * M, D, xif);
+        } else {
+          float* dst = sl + (int64_t)b * BLK + w * CAP + lane * M;
+#pragma unroll
+          for (int j = 0; j < M; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(ln.k[j], ln.k[j + 1], ln.k[j + 2], ln.k[j + 3]);
+        }
+      }
+      sync_scratch();
+    }
+    acc = wave_sum_h(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot += red[q];
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+    __syncthreads();
+  }
+}
+
+// unit weights, tau <= 1: the rows above FSW_HUB_MAX_DEG.  scratch: fsw_embed_scratch_bytes(max_degree).
+int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  if (rows_upper <= 0 || (a.max_degree > 0 && a.max_degree <= FSW_HUB_MAX_DEG)) return 0;
+  FSW_REQUIRE(a.max_degree > FSW_HUB_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_HUB_MAX_DEG");
+  FSW_REQUIRE(a.scratch, "fsw_embed_f32: rows above FSW_HUB_MAX_DEG need a scratch buffer (fsw_embed_scratch_bytes)");
+  const int64_t line_floats = ceil_div(a.max_degree, kGiantBlk) * kGiantBlk;
+  int64_t nwg = std::min<int64_t>((int64_t)(a.scratch_bytes / (size_t)(line_floats * 4)), 256 * (16 / kGiantNW));   // every CU full
+  nwg = std::min<int64_t>(nwg, ceil_div(rows_upper * a.S, 8) * 8);
+  if (nwg >= 8) nwg &= ~(int64_t)7;
+  FSW_REQUIRE(nwg >= 1, "fsw_embed_f32: scratch buffer too small for rows above FSW_HUB_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
+  FSW_REQUIRE(((uintptr_t)a.scratch & 15) == 0, "fsw_embed_f32: scratch must be 16-byte aligned");
+  k_embed_giant<<<(unsigned)nwg, kGiantNW * kWave, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo,
+                                                                a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
+                                                                reinterpret_cast<float*>(a.scratch), line_floats);
+  FSW_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int NW, int M>

@@ -417,15 +417,12 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
   }
 }
 
-// unit weights (tau <= 1): only the rows above FSW_HUB_MAX_DEG come here (embed_hub.hip takes the hub bins); general
-// weights: every row above FSW_LDS_MAX_DEG
-int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
+int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);   // embed_hub.hip
 
+// general weights: every row above FSW_LDS_MAX_DEG (unit weights with tau <= 1 take embed_hub.hip's kernels)
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
-  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f);
   FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
-  if (unit_fast && a.max_degree <= FSW_HUB_MAX_DEG) return 0;
   FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
   const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
   const int64_t wave_bytes = Dp * 8;
@@ -434,14 +431,9 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
   nwaves = nwaves >= 32 ? (nwaves & ~(int64_t)31) : (nwaves & ~(int64_t)3);   // whole workgroups; a multiple of 8 of them when possible
   FSW_REQUIRE(nwaves >= 4, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
   char* scratch = reinterpret_cast<char*>(a.scratch);
-  if (unit_fast)
-    k_embed_wsort_global<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
-        FSW_BIN_GLOBAL);
-  else
-    k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
-        FSW_BIN_HUB0);
+  k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
+      a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
+      FSW_BIN_HUB0);
   FSW_LAUNCH_CHECK();
   return 0;
 }

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--weighted", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", help="substring of the class name to time")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, S, d = 1 << args.scale, args.slices, args.feat
@@ -61,6 +62,8 @@ def main():
                ("ws 1025..2048", 1024, 2048), ("hub 2049..4096", 2048, 4096), ("hub 4097..8192", 4096, 8192),
                ("hub 8193..16384", 8192, 16384), ("hub 16385..32768", 16384, 32768), ("global > 32768", 32768, 1 << 30)]
     for name, lo, hi in classes:
+        if args.only and args.only not in name:
+            continue
         keep = (degt[ei[1]] > lo) & (degt[ei[1]] <= hi)
         edges = int(keep.sum())
         if edges == 0:
