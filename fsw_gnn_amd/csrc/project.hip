@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
 // the three bf16 planes of its 32-column weight slab in registers, X tiles are split once when they enter LDS.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int B3_LD = 136;  // bf16 per LDS row: 128 + 8 (16-byte pad)
+// bf16 per LDS row of the A planes: 16 KS + 8 (16-byte pad: row stride = 4 banks mod 64, conflict-free 16-byte fragment reads)
 #ifndef FSW_PROJECT_ABL
 #define FSW_PROJECT_ABL 0   // timing experiments (tools/exp_variants.sh): 1 = no MFMA, 2 = no output stores
 #endif
@@ -263,7 +263,7 @@ __device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c)
 }
 
 template <int KS>
-__global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+__global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
                                                      const float* __restrict__ V, int S, int64_t ldv,
                                                      float* __restrict__ Xp, int64_t ldp, int32_t* __restrict__ stats,
                                                      float* __restrict__ x_copy, int64_t ld_copy,
@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
                                                      const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
                                                      const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves,
                                                      int nsl1, int y2_vec) {
+  // KS <= 8 (d <= 128): up to 12 slab waves keep their whole slab of [V; W2] in registers (24 KS registers each).
+  // KS == 16 (d <= 256): the slab takes 192 registers, so a workgroup is 4 slab waves + 4 waves that only move X, two waves
+  // per SIMD at up to 256 registers, and the column groups beyond the first re-read X (from L2 / the Infinity Cache mostly).
+  constexpr int B3_LD = 16 * KS + 8;
+  constexpr int NQ = KS <= 8 ? 2 : 4;     // float4 of an X tile per thread (32 rows x 4 KS float4 over >= 512 threads)
   // LDS: A planes [2][3][32][B3_LD] bf16 | C staging [2][32][ldc] float | row map [2][32] int
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 (*APlanes)[3][BS_ROWS][B3_LD];
@@ -310,37 +315,37 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
   }
   const float add = (col_ok && second && b2) ? b2[c] : 0.f;
 
-  for (int i = threadIdx.x; i < 2 * 3 * BS_ROWS * B3_LD / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  for (int i = threadIdx.x; i < 2 * 3 * BS_ROWS * B3_LD / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(smem)[i] = 0u;   // k padding
   __syncthreads();
 
   const int d4 = d >> 2;
   const int per_tile = BS_ROWS * d4;
   int nonfinite = 0;
-  auto load_tile = [&](int64_t tile, float4& q0, float4& q1) {
+  struct TileRegs {
+    float4 q[NQ];
+  };
+  auto load_tile = [&](int64_t tile, TileRegs& t) {
     const int64_t row0 = tile * BS_ROWS;
-    q0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    q1 = q0;
-    const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
-    if (i0 < per_tile) {
-      const int r = i0 / d4, c4 = i0 - r * d4;
-      if (row0 + r < n) q0 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
-    }
-    if (i1 < per_tile) {
-      const int r = i1 / d4, c4 = i1 - r * d4;
-      if (row0 + r < n) q1 = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      t.q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int i = threadIdx.x + u * blockDim.x;
+      if (i < per_tile) {
+        const int r = i / d4, c4 = i - r * d4;
+        if (row0 + r < n) t.q[u] = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
+      }
     }
   };
-  auto store_tile = [&](int buf, int64_t tile, const float4& q0, const float4& q1) {
+  auto store_tile = [&](int buf, int64_t tile, const TileRegs& t) {
     const int64_t row0 = tile * BS_ROWS;
     if (threadIdx.x < BS_ROWS)
       rmap[buf * BS_ROWS + threadIdx.x] = (row_map && row0 + threadIdx.x < n) ? row_map[row0 + threadIdx.x] : (int)(row0 + threadIdx.x);
-    const int idx[2] = {(int)threadIdx.x, (int)(threadIdx.x + blockDim.x)};
-    const float4 q[2] = {q0, q1};
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (idx[u] < per_tile) {
-        const int r = idx[u] / d4, c4 = idx[u] - r * d4;
-        const float v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+    for (int u = 0; u < NQ; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      if (i < per_tile) {
+        const int r = i / d4, c4 = i - r * d4;
+        const float v[4] = {t.q[u].x, t.q[u].y, t.q[u].z, t.q[u].w};
         bf16x4 p1, p2, p3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -393,18 +398,18 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
   // of iteration t; the HBM loads of tile t+2 are issued right after and have the whole iteration to land.  The C
   // tile is double buffered too, so one barrier per tile orders everything.
   int64_t tile = blockIdx.x;
-  float4 q0, q1;
+  TileRegs tr;
   if (tile < ntiles) {
-    load_tile(tile, q0, q1);
-    store_tile(0, tile, q0, q1);
+    load_tile(tile, tr);
+    store_tile(0, tile, tr);
   }
-  if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, q0, q1);
+  if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, tr);
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
     const int64_t next = tile + gridDim.x, next2 = next + gridDim.x;
-    if (next < ntiles) store_tile(buf ^ 1, next, q0, q1);
-    if (next2 < ntiles) load_tile(next2, q0, q1);
+    if (next < ntiles) store_tile(buf ^ 1, next, tr);
+    if (next2 < ntiles) load_tile(next2, tr);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -432,8 +437,8 @@ __global__ void __launch_bounds__(768) k_project_bf3(const float* __restrict__ X
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
 }
 
-static size_t bf3_lds_bytes(int nwaves) {
-  return sizeof(__bf16) * 2 * 3 * BS_ROWS * B3_LD + sizeof(float) * 2 * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
+static size_t bf3_lds_bytes(int nwaves, int ks) {
+  return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * 2 * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
 }
 
 }  // namespace fsw
@@ -450,14 +455,15 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
   FSW_REQUIRE(H2 == 0 || (W2 && Y2 && ldw2 >= d && ldy2 >= H2), "fsw_project: bad second output block");
   const bool vec = (ldx % 4 == 0) && (ldv % 4 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                    (H2 == 0 || ((ldw2 % 4 == 0) && ((uintptr_t)W2 % 16 == 0)));
-  if (vec && d % 4 == 0 && d <= 128) {
-    // B-stationary kernels: one wave per 32-column slab, persistent over 32-row tiles (<= 12 slab waves so that the
-    // B-operand registers fit without spilling; >= 8 waves so that every X tile is two 16-byte loads per thread --
-    // waves without a slab only help moving X)
-    const bool exact = getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
+  if (vec && d % 4 == 0 && d <= 256) {
+    // B-stationary kernels: one wave per 32-column slab, persistent over 32-row tiles (d <= 128: <= 12 slab waves so that
+    // the B-operand registers fit without spilling, d <= 256: 4; >= 8 waves so that every X tile is two / four 16-byte
+    // loads per thread -- waves without a slab only help moving X)
+    const bool exact = d <= 128 && getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
     const int nsl1 = (int)ceil_div(S, 32), nsl2 = (int)ceil_div(H2, 32);
     const int nslabs = exact ? (int)ceil_div(S + H2, 32) : nsl1 + nsl2;
-    const int ngroups = (int)ceil_div(nslabs, 12);
+    const int max_slab_waves = d <= 128 ? 12 : 4;
+    const int ngroups = (int)ceil_div(nslabs, max_slab_waves);
     const int nwaves = (int)ceil_div(nslabs, ngroups);
     const int64_t ntiles = ceil_div(n, BS_ROWS);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, 256), (unsigned)ngroups);
@@ -475,7 +481,8 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
       FSW_REQUIRE(ldp >= (int64_t)nsl1 * 32 && ldp % 4 == 0 && (uintptr_t)Xp % 16 == 0,
                   "fsw_project: Xp must be 16-byte aligned with ldp >= 32*ceil(S/32), ldp %% 4 == 0");
       const int y2_vec = (H2 > 0 && ldy2 % 4 == 0 && (uintptr_t)Y2 % 16 == 0) ? 1 : 0;
-      const size_t lds = bf3_lds_bytes(nwaves);
+      const int ks = d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16;
+      const size_t lds = bf3_lds_bytes(nwaves, ks);
 #define FSW_LAUNCH_BF3(KS)                                                                                                  \
   do {                                                                                                                      \
     FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_project_bf3<KS>),                                     \
@@ -483,9 +490,10 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
     k_project_bf3<KS><<<grid, threads, lds, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, \
                                                       b2, Y2, ldy2, row_map, ntiles, nwaves, nsl1, y2_vec);                 \
   } while (0)
-      if (d <= 32) FSW_LAUNCH_BF3(2);
-      else if (d <= 64) FSW_LAUNCH_BF3(4);
-      else FSW_LAUNCH_BF3(8);
+      if (ks == 2) FSW_LAUNCH_BF3(2);
+      else if (ks == 4) FSW_LAUNCH_BF3(4);
+      else if (ks == 8) FSW_LAUNCH_BF3(8);
+      else FSW_LAUNCH_BF3(16);
 #undef FSW_LAUNCH_BF3
     }
     FSW_LAUNCH_CHECK();

@@ -54,7 +54,9 @@ def test_projection_mfma_vs_float64(dev):
     from fsw_gnn_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(0)
-    for n, d, S in ((1000, 64, 32), (777, 13, 70), (4096, 128, 256), (130, 3, 129)):
+    # d <= 256 with 16-byte aligned rows: bf16x3 matrix-core kernels (k-blocked weight slabs above 128); the rest: generic kernel
+    for n, d, S in ((1000, 64, 32), (777, 13, 70), (4096, 128, 256), (130, 3, 129), (3000, 192, 256), (5000, 256, 256), (999, 256, 40),
+                    (640, 200, 130), (300, 260, 64)):
         X = rng.standard_normal((n, d)).astype(np.float32)
         V = rng.standard_normal((S, d)).astype(np.float32)
         Xd, Vd = t(X, dev), t(V, dev)
