@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--edges", type=int, default=N_EDGES)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-segcumsum", action="store_true", help="skip the stand-alone segmented-cumsum throughput leg")
     ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
@@ -251,6 +252,22 @@ def node_sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world):
             "ms_per_launch": kms}
 
 
+def segcumsum_leg(dev, reps=5, elems=256_000_000, mean_seg=10.0):
+    """The stand-alone segmented cumulative sum (fsw_segcumsum, the replacement of the reference's only native kernel,
+    fsw_embedding.cu) on float32 values / int64 ids with neighbourhood-sized segments: GB/s of algorithmic bytes
+    (value read + id read + value written = 16 B per element) against the HBM peak."""
+    from fsw_gnn_amd import segcumsum
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    ids = torch.cumsum(torch.rand(elems, device=dev, generator=g) < (1.0 / mean_seg), 0, dtype=torch.int64)
+    vals = torch.rand(elems, device=dev, generator=g)
+    ms = timed_ms(lambda: segcumsum(vals, ids), reps, dev)
+    gbs = elems * 16.0 / ms / 1e6
+    return {"kernel": "k_segscan_chained", "elements": elems, "mean_segment": mean_seg, "values": "f32", "ids": "i64", "ms": ms,
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_element": 16}
+
+
 def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     """C oracle (port of the reference algorithm) on the host cores: slices [0, nslices) of the same workload."""
     from oracle import c_oracle as C
@@ -370,6 +387,10 @@ def main():
         roof, ms = dominant_kernel_roofline(conv, x, ei, n, e_coalesced, args.kernel_reps, dev)
         result["roofline"] = roof
         result["stage_ms"] = ms
+        if not args.no_segcumsum:
+            del y
+            torch.cuda.empty_cache()
+            result["segcumsum"] = segcumsum_leg(dev)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
     if world > 1:

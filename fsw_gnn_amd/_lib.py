@@ -71,6 +71,10 @@ _SIGNATURES = {
     "segcumsum_wrapper": (None, [c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, ctypes.c_bool, c_i64, c_i64, c_sz]),
     "add_block_sums_wrapper": (None, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64]),
     "get_max_threads_per_block": (ctypes.c_int, [ctypes.c_int]),
+    "launch_segcumsum_kernel_float": (None, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, ctypes.c_bool, c_i64, c_i64, c_i64]),
+    "launch_segcumsum_kernel_double": (None, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, ctypes.c_bool, c_i64, c_i64, c_i64]),
+    "launch_add_block_sums_kernel_float": (None, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64]),
+    "launch_add_block_sums_kernel_double": (None, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

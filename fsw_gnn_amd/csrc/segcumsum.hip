@@ -3,23 +3,33 @@
 // fsw_segcumsum replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): the
 // reference scans each 256-element block with a Hillis-Steele loop in shared memory that re-reads the
 // int64 ids from global memory every round, then recurses over block sums level by level with a
-// device-wide synchronise around every launch (fsw_embedding.cu:34-117, 194-228).  Here the scan is a
-// reduce-then-scan over (sum, segment-head flag) pairs, which form a monoid
-//        (s1, f1) . (s2, f2) = (f2 ? s2 : s1 + s2,  f1 | f2)
-// so wavefront shuffles (64 lanes) do the in-block work, no id is read more than twice, and the whole
-// thing is three stream-ordered launches whatever the input size:
-//   k_tile_reduce  per 2048-element tile: aggregate of the tile
-//   k_tile_scan    one workgroup: exclusive scan of the tile aggregates (carry into every tile)
-//   k_tile_apply   per tile: in-register scan seeded with the tile's carry, written in place or out of place
+// device-wide synchronise around every launch (fsw_embedding.cu:34-117, 194-228): >= 28 bytes of HBM
+// traffic per element and 9 launches at 2.56e9 elements.  Here the scan is ONE streaming pass (chained
+// scan with decoupled look-back) over (sum, segment-head flag) pairs, which form a monoid
+//        (s1, f1) . (s2, f2) = (f2 ? s2 : s1 + s2,  f1 | f2):
+// every element is read once and written once (4 + 8 + 4 bytes for float32 values / int64 ids).
+//   * a persistent grid (a fixed number of workgroups per CU, all co-resident) walks the tiles in order:
+//     workgroup g takes tiles g, g + G, g + 2G, ...  Every predecessor of a tile is therefore owned by a
+//     resident workgroup that reaches it first -- no ticket counter, no dependence on dispatch order;
+//   * per tile: 16-byte loads of a thread's 16 (float32) / 8 (float64) consecutive elements, in-register
+//     scan, wavefront shuffles across the threads, then the tile publishes its AGGREGATE in a 64-bit
+//     descriptor word {status | flag, value bits} with one relaxed agent-scope store (an 8-byte granule: no
+//     fence; float64 sums take two tagged words), looks back over its predecessors 64 at a time -- the walk
+//     stops at the first tile that holds a segment head or has published its inclusive PREFIX -- and
+//     publishes its own prefix.  With the short segments of the FSW path (one neighbourhood, ~10 elements)
+//     the walk ends at the immediate predecessor's aggregate, which depends on nothing but that tile's data.
 // A head is an element whose id differs from its predecessor's (successor's when reverse != 0), exactly
 // the restart rule of segcumsum_slow (fsw_embedding.py:3016-3027).
+#include <algorithm>
 #include "fsw_common.h"
 
 namespace fsw {
 
 constexpr int kSegThreads = 256;
-constexpr int kSegItems = 8;
-constexpr int kSegTile = kSegThreads * kSegItems;
+#ifndef FSW_SEG_WG_PER_CU
+#define FSW_SEG_WG_PER_CU 6
+#endif
+constexpr int kSegMaxWgPerCu = FSW_SEG_WG_PER_CU;
 
 template <class V>
 struct SegPair {
@@ -64,106 +74,242 @@ __device__ __forceinline__ SegPair<V> block_segscan(SegPair<V> v, SegPair<V>* wa
   return wv ? seg_combine(carry, v) : v;
 }
 
-template <class I>
-__device__ __forceinline__ bool is_head(const I* __restrict__ ids, int64_t i, int64_t n, bool reverse) {
-  // i is the LOGICAL position (scan order); memory position is n-1-i when scanning from the end
-  if (i == 0) return true;
-  const int64_t a = reverse ? n - 1 - i : i;
-  const int64_t b = reverse ? a + 1 : a - 1;
-  return ids[a] != ids[b];
-}
-
-template <class V, class I>
-__global__ void __launch_bounds__(kSegThreads) k_tile_reduce(const V* __restrict__ values, const I* __restrict__ ids,
-                                                             int64_t n, int reverse, V* __restrict__ tile_sum,
-                                                             int* __restrict__ tile_flag) {
-  __shared__ SegPair<V> wave_tot[16];
-  const int64_t base = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
-  SegPair<V> agg;
-  agg.s = V(0);
-  agg.f = 0;
-#pragma unroll
-  for (int j = 0; j < kSegItems; ++j) {
-    const int64_t i = base + j;
-    if (i < n) {
-      SegPair<V> e;
-      e.s = values[reverse ? n - 1 - i : i];
-      e.f = is_head(ids, i, n, reverse);
-      agg = seg_combine(agg, e);
-    }
-  }
-  agg = block_segscan(agg, wave_tot);
-  if (threadIdx.x == kSegThreads - 1) {
-    tile_sum[blockIdx.x] = agg.s;
-    tile_flag[blockIdx.x] = agg.f;
-  }
-}
-
+// ---- tile descriptors ------------------------------------------------------------------------------------
+// tag = status (1 aggregate, 2 inclusive prefix) | flag << 2 in the high half of every 64-bit word, 32 value bits in the
+// low half: float32 sums one word, float64 sums two (low / high half of the double), both carrying the same tag.
+constexpr unsigned kDescAggregate = 1u, kDescPrefix = 2u;
 template <class V>
-__global__ void __launch_bounds__(kSegThreads) k_tile_scan(V* __restrict__ tile_sum, int* __restrict__ tile_flag, int64_t nt) {
-  // in-place: tile_sum[b] becomes the carry entering tile b (exclusive segmented scan of the aggregates)
-  __shared__ SegPair<V> wave_tot[16];
-  __shared__ SegPair<V> incl[kSegThreads];
-  SegPair<V> run;
-  run.s = V(0);
-  run.f = 0;
-  for (int64_t a = 0; a < nt; a += kSegThreads) {
-    const int64_t i = a + threadIdx.x;
-    SegPair<V> v;
-    v.s = i < nt ? tile_sum[i] : V(0);
-    v.f = i < nt ? tile_flag[i] : 0;
-    SegPair<V> sc = block_segscan(v, wave_tot);
-    incl[threadIdx.x] = sc;
-    __syncthreads();
-    SegPair<V> ex = run;
-    if (threadIdx.x > 0) ex = seg_combine(run, incl[threadIdx.x - 1]);
-    if (i < nt) tile_sum[i] = ex.s;
-    run = seg_combine(run, incl[kSegThreads - 1]);
-    __syncthreads();
-  }
+struct DescWords {
+  static constexpr int kWords = sizeof(V) == 4 ? 1 : 2;
+};
+
+__device__ __forceinline__ void desc_store(unsigned long long* d, float v, unsigned tag) {
+  __hip_atomic_store(d, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void desc_store(unsigned long long* d, double v, unsigned tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(d, ((unsigned long long)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(d + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns the tag (0 = not published yet, or the two words of a float64 descriptor disagree: poll again)
+__device__ __forceinline__ unsigned desc_load(const unsigned long long* d, float& v) {
+  const unsigned long long w = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __uint_as_float((unsigned)w);
+  return (unsigned)(w >> 32);
+}
+__device__ __forceinline__ unsigned desc_load(const unsigned long long* d, double& v) {
+  const unsigned long long w0 = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long w1 = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+  return (w0 >> 32) == (w1 >> 32) ? (unsigned)(w0 >> 32) : 0u;
 }
 
-template <class V, class I>
-__global__ void __launch_bounds__(kSegThreads) k_tile_apply(const V* __restrict__ values, V* __restrict__ out,
-                                                            const I* __restrict__ ids, int64_t n, int reverse,
-                                                            const V* __restrict__ tile_carry) {
-  __shared__ SegPair<V> wave_tot[16];
-  __shared__ V incl[kSegThreads];
-  const int64_t base = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
-  V val[kSegItems];
-  int head[kSegItems];
-  SegPair<V> agg;
-  agg.s = V(0);
-  agg.f = 0;
+// ---- the single-pass kernel ----------------------------------------------------------------------------------
+// Data layout of a tile (TILE = 4 wavefronts x WCH elements): wavefront wv owns memory offsets [wv * WCH, (wv + 1) * WCH) of
+// the tile's memory range, and inside it lane l holds, for q < Q, the four elements q * 256 + 4 l .. 4 l + 3: every
+// wave-instruction reads or writes 64 x 16 B of CONSECUTIVE memory (32 B per lane for 8-byte items).  The scan runs in logical order,
+// which is memory order when !REV and the exact mirror image when REV (waves, q, lanes and the four elements of a lane
+// all descending), so one code path with mirrored indices serves both directions.
+// VEC: 16-byte accesses (pointers 16-byte aligned and the tile's memory range starting on a multiple of 4 elements).
+template <bool REV>
+__device__ __forceinline__ int logical_lane() { return REV ? kWave - 1 - lane_id() : lane_id(); }
+
+// value of the logically previous lane (undefined for logical lane 0)
+template <bool REV, class T>
+__device__ __forceinline__ T from_prev_lane(T v, int off = 1) { return REV ? __shfl_down(v, off) : __shfl_up(v, off); }
+
+template <bool REV, class V>
+__device__ __forceinline__ SegPair<V> wave_segscan_dir(SegPair<V> v) {
+  const int ll = logical_lane<REV>();
 #pragma unroll
-  for (int j = 0; j < kSegItems; ++j) {
-    const int64_t i = base + j;
-    val[j] = V(0);
-    head[j] = 0;
-    if (i < n) {
-      val[j] = values[reverse ? n - 1 - i : i];
-      head[j] = is_head(ids, i, n, reverse);
-    }
-    SegPair<V> e;
-    e.s = val[j];
-    e.f = head[j];
-    agg = seg_combine(agg, e);
+  for (int off = 1; off < kWave; off <<= 1) {
+    SegPair<V> l;
+    l.s = from_prev_lane<REV>(v.s, off);
+    l.f = from_prev_lane<REV>(v.f, off);
+    if (ll >= off) v = seg_combine(l, v);
   }
-  SegPair<V> sc = block_segscan(agg, wave_tot);
-  incl[threadIdx.x] = sc.s;
-  __syncthreads();
-  // running sum entering this thread: the previous thread's inclusive value (which already restarts at
-  // heads) plus the tile carry when no head precedes this thread inside the tile
-  __shared__ int inclf[kSegThreads];
-  inclf[threadIdx.x] = sc.f;
-  __syncthreads();
-  V run = tile_carry[blockIdx.x];
-  if (threadIdx.x > 0) run = inclf[threadIdx.x - 1] ? incl[threadIdx.x - 1] : incl[threadIdx.x - 1] + run;
+  return v;
+}
+
+template <class V, class I, bool REV, bool VEC>
+__global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
+                                                                 const I* __restrict__ ids, int64_t n,
+                                                                 unsigned long long* __restrict__ desc, int64_t ntiles) {
+  constexpr int Q = sizeof(V) == 4 ? 4 : 2;           // 16 (float32) / 8 (float64) elements per thread
+  constexpr int WCH = kWave * 4 * Q;                  // elements per wavefront and tile
+  constexpr int NWV = kSegThreads / kWave;
+  constexpr int TILE = NWV * WCH;
+  constexpr int DW = DescWords<V>::kWords;
+  __shared__ SegPair<V> wave_tot[NWV];
+  __shared__ V carry_s;
+  const int lane = lane_id(), wv = wave_id();
+  const int ll = logical_lane<REV>();
+  const int lwv = REV ? NWV - 1 - wv : wv;            // logical wave index
+  const int lastlane = REV ? 0 : kWave - 1;           // physical lane that is logically last
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // memory range of the tile: [M0, M0 + TILE); logical element L of the whole array sits at memory n - 1 - L when REV
+    const int64_t M0 = REV ? n - (tile + 1) * TILE : tile * TILE;
+    const int64_t mw = M0 + (int64_t)wv * WCH;        // this wavefront's memory range starts here
+    V val[Q][4];
+    I id[Q][4];
+    const bool whole = M0 >= 0 && M0 + TILE <= n;
 #pragma unroll
-  for (int j = 0; j < kSegItems; ++j) {
-    const int64_t i = base + j;
-    run = head[j] ? val[j] : run + val[j];
-    if (i < n) out[reverse ? n - 1 - i : i] = run;
+    for (int q = 0; q < Q; ++q) {
+      const int64_t m = mw + q * 256 + lane * 4;
+      if (VEC && whole) {
+        typedef V vecv __attribute__((ext_vector_type(4)));
+        typedef I veci __attribute__((ext_vector_type(4)));
+        const vecv tv = *reinterpret_cast<const vecv*>(values + m);
+        const veci ti = *reinterpret_cast<const veci*>(ids + m);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          val[q][u] = tv[u];
+          id[q][u] = ti[u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = m + u >= 0 && m + u < n;
+          val[q][u] = ok ? values[m + u] : V(0);
+          id[q][u] = ok ? ids[m + u] : I(0);
+        }
+      }
+    }
+    // id of the element logically just before this wavefront's chunk (wave-uniform)
+    const int64_t L0 = tile * TILE + (int64_t)lwv * WCH;          // first logical element of the chunk
+    const bool chunk_has_prev = L0 > 0 && L0 < n;
+    I idchunk = I(0);
+    if (chunk_has_prev) idchunk = ids[REV ? n - L0 : L0 - 1];
+    // heads and the lane-local scans, q in logical order
+    SegPair<V> pre[Q];      // everything of this wavefront's chunk that logically precedes the lane's four elements of q
+    SegPair<V> wcarry;      // running aggregate of the chunk
+    wcarry.s = V(0);
+    wcarry.f = 0;
+    unsigned heads = 0;     // bit q * 4 + u
+#pragma unroll
+    for (int lq = 0; lq < Q; ++lq) {
+      const int q = REV ? Q - 1 - lq : lq;
+      const int ul = REV ? 0 : 3;                                  // logically last of the lane's four
+      // predecessor id of the lane's logically first element
+      I idp = from_prev_lane<REV>(id[q][ul]);
+      bool has_prev = true;
+      if (lq == 0) {
+        if (ll == 0) {
+          idp = idchunk;
+          has_prev = chunk_has_prev;
+        }
+      } else {
+        const int qp = REV ? q + 1 : q - 1;
+        const I wrap = __shfl(id[qp][ul], lastlane);
+        if (ll == 0) idp = wrap;
+      }
+      SegPair<V> agg;
+      agg.s = V(0);
+      agg.f = 0;
+#pragma unroll
+      for (int lu = 0; lu < 4; ++lu) {
+        const int u = REV ? 3 - lu : lu;
+        const int64_t m = mw + q * 256 + lane * 4 + u;
+        const bool valid = m >= 0 && m < n;
+        bool head;
+        if (lu == 0) head = !has_prev || id[q][u] != idp;
+        else head = id[q][u] != id[q][REV ? u + 1 : u - 1];
+        head = head && valid;
+        heads |= (unsigned)head << (q * 4 + u);
+        SegPair<V> e;
+        e.s = valid ? val[q][u] : V(0);
+        e.f = head;
+        agg = seg_combine(agg, e);
+      }
+      const SegPair<V> inc = wave_segscan_dir<REV>(agg);            // inclusive over the lanes, logical order
+      SegPair<V> ex;
+      ex.s = from_prev_lane<REV>(inc.s);
+      ex.f = from_prev_lane<REV>(inc.f);
+      if (ll == 0) {
+        ex.s = V(0);
+        ex.f = 0;
+      }
+      pre[q] = seg_combine(wcarry, ex);
+      SegPair<V> tot;
+      tot.s = __shfl(inc.s, lastlane);
+      tot.f = __shfl(inc.f, lastlane);
+      wcarry = seg_combine(wcarry, tot);
+    }
+    // across the wavefronts of the tile
+    if (lane == 0) wave_tot[lwv] = wcarry;
+    __syncthreads();
+    SegPair<V> wpre, tagg;
+    wpre.s = V(0);
+    wpre.f = 0;
+    tagg = wpre;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      if (i == lwv) wpre = tagg;
+      tagg = seg_combine(tagg, wave_tot[i]);
+    }
+    if (threadIdx.x == 0) {   // the tile's aggregate
+      if (tile == 0) desc_store(desc, tagg.s, kDescPrefix | ((unsigned)tagg.f << 2));
+      else desc_store(desc + tile * DW, tagg.s, kDescAggregate | ((unsigned)tagg.f << 2));
+    }
+    // decoupled look-back by wavefront 0: 64 predecessors per step, newest in lane 0
+    if (wv == 0) {
+      V carry = V(0);
+      int64_t t0 = tile - 1;
+      bool done = tile == 0;
+      while (!done) {
+        const int64_t t = t0 - lane;
+        V dv = V(0);
+        unsigned tag = kDescPrefix;                 // lanes before tile 0: a stopper that contributes nothing
+        if (t >= 0) {
+          do {
+            tag = desc_load(desc + t * DW, dv);
+            if ((tag & 3u) == 0) __builtin_amdgcn_s_sleep(1);
+          } while ((tag & 3u) == 0);
+        }
+        const bool stop = (tag & 3u) == kDescPrefix || (tag & 4u);
+        const unsigned long long sm = __ballot(stop);
+        const int lstop = sm ? __ffsll((long long)sm) - 1 : kWave;     // first (newest) stopper
+        V part = (lane <= lstop && t >= 0) ? dv : V(0);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        carry = part + carry;
+        done = sm != 0;
+        t0 -= kWave;
+      }
+      if (lane == 0) {
+        carry_s = carry;
+        if (tile > 0) desc_store(desc + tile * DW, tagg.f ? tagg.s : carry + tagg.s, kDescPrefix | ((unsigned)tagg.f << 2));
+      }
+    }
+    __syncthreads();
+    SegPair<V> tc;
+    tc.s = carry_s;
+    tc.f = 0;
+    const SegPair<V> wenter = seg_combine(tc, wpre);               // everything before this wavefront's chunk
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      V r = seg_combine(wenter, pre[q]).s;
+      V res[4];
+#pragma unroll
+      for (int lu = 0; lu < 4; ++lu) {
+        const int u = REV ? 3 - lu : lu;
+        r = ((heads >> (q * 4 + u)) & 1u) ? val[q][u] : r + val[q][u];
+        res[u] = r;
+      }
+      const int64_t m = mw + q * 256 + lane * 4;
+      if (VEC && whole) {
+        typedef V vecv __attribute__((ext_vector_type(4)));
+        vecv tv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tv[u] = res[u];
+        *reinterpret_cast<vecv*>(out + m) = tv;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (m + u >= 0 && m + u < n) out[m + u] = res[u];
+      }
+    }
+    __syncthreads();   // carry_s / wave_tot are reused by the next tile
   }
 }
 
@@ -196,18 +342,38 @@ __global__ void k_legacy_add_block_sums(V* __restrict__ output, const V* __restr
   if (i < size && blockIdx.x >= 1 && block_last_id[blockIdx.x - 1] == segment_ids[i]) output[i] += block_sums[blockIdx.x - 1];
 }
 
-template <class V, class I>
-static int run_segcumsum(const void* values, void* out, const void* ids, int64_t n, int reverse, void* ws, hipStream_t stream) {
-  const int64_t nt = ceil_div(n, kSegTile);
-  V* tile_sum = reinterpret_cast<V*>(ws);
-  int* tile_flag = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + ((sizeof(double) * (size_t)nt + 255) / 256) * 256);
-  k_tile_reduce<V, I><<<(unsigned)nt, kSegThreads, 0, stream>>>((const V*)values, (const I*)ids, n, reverse, tile_sum, tile_flag);
-  FSW_LAUNCH_CHECK();
-  k_tile_scan<V><<<1, kSegThreads, 0, stream>>>(tile_sum, tile_flag, nt);
-  FSW_LAUNCH_CHECK();
-  k_tile_apply<V, I><<<(unsigned)nt, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, reverse, tile_sum);
+template <class V>
+static int64_t seg_tile_elems() { return (int64_t)kSegThreads * (sizeof(V) == 4 ? 16 : 8); }   // = TILE of k_segscan_chained
+
+template <class V, class I, bool REV>
+static int launch_segscan(const void* values, void* out, const void* ids, int64_t n, void* ws, hipStream_t stream) {
+  const int64_t ntiles = ceil_div(n, seg_tile_elems<V>());
+  unsigned long long* desc = reinterpret_cast<unsigned long long*>(ws);
+  FSW_CHECK_HIP(hipMemsetAsync(desc, 0, sizeof(unsigned long long) * DescWords<V>::kWords * (size_t)ntiles, stream));
+  // persistent grid: every workgroup must be resident (the look-back spins on predecessors).  4 workgroups of 256
+  // threads per CU need <= 128 registers and no LDS to speak of; the occupancy query guards against surprises.
+  static int grid_cache = 0;
+  if (!grid_cache) {
+    int dev = 0, cus = 0, per_cu = 0;
+    FSW_CHECK_HIP(hipGetDevice(&dev));
+    FSW_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    FSW_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_segscan_chained<V, I, REV, true>, kSegThreads, 0));
+    grid_cache = std::max(1, cus) * std::max(1, std::min(per_cu - 1, kSegMaxWgPerCu));   // one below the query: it can be one high (MI355X guide)
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, grid_cache);
+  // 16-byte accesses: aligned pointers, and when scanning from the end the tiles must start on a multiple of 4 elements
+  const bool vec = ((uintptr_t)values % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)ids % 16 == 0) && (!REV || n % 4 == 0);
+  if (vec)
+    k_segscan_chained<V, I, REV, true><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles);
+  else
+    k_segscan_chained<V, I, REV, false><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles);
   FSW_LAUNCH_CHECK();
   return 0;
+}
+
+template <class V, class I>
+static int run_segcumsum(const void* values, void* out, const void* ids, int64_t n, int reverse, void* ws, hipStream_t stream) {
+  return reverse ? launch_segscan<V, I, true>(values, out, ids, n, ws, stream) : launch_segscan<V, I, false>(values, out, ids, n, ws, stream);
 }
 
 }  // namespace fsw
@@ -215,17 +381,18 @@ static int run_segcumsum(const void* values, void* out, const void* ids, int64_t
 using namespace fsw;
 
 extern "C" size_t fsw_segcumsum_workspace_bytes(int64_t n) {
-  const size_t nt = (size_t)ceil_div(n > 0 ? n : 1, kSegTile);
-  return ((sizeof(double) * nt + 255) / 256) * 256 + ((sizeof(int) * nt + 255) / 256) * 256;
+  const size_t nt = (size_t)ceil_div(n > 0 ? n : 1, (int64_t)kSegThreads * 8);   // the smaller (float64) tile
+  return ((2 * sizeof(unsigned long long) * nt + 255) / 256) * 256;
 }
 
 extern "C" int fsw_segcumsum(int value_dtype, const void* values, void* out, const void* segment_ids, int id_bytes, int64_t n,
                              int reverse, void* workspace, size_t workspace_bytes, fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (n == 0) return 0;
-  FSW_REQUIRE(n > 0 && ceil_div(n, kSegTile) < (1ll << 31), "fsw_segcumsum: bad size %lld", (long long)n);
+  FSW_REQUIRE(n > 0 && n < (1ll << 40), "fsw_segcumsum: bad size %lld", (long long)n);
   FSW_REQUIRE(values && out && segment_ids && workspace, "fsw_segcumsum: null pointer");
   FSW_REQUIRE(workspace_bytes >= fsw_segcumsum_workspace_bytes(n), "fsw_segcumsum: workspace too small");
+  FSW_REQUIRE(((uintptr_t)workspace & 7) == 0, "fsw_segcumsum: workspace must be 8-byte aligned");
   FSW_REQUIRE((value_dtype == 0 || value_dtype == 1) && (id_bytes == 4 || id_bytes == 8),
               "fsw_segcumsum: value_dtype must be 0 (float32) or 1 (float64), id_bytes 4 or 8");
   reverse = reverse ? 1 : 0;
@@ -273,6 +440,41 @@ extern "C" void add_block_sums_wrapper(int dtype, void* output, const void* bloc
     k_legacy_add_block_sums<double><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(
         (double*)output, (const double*)block_sums, segment_ids, block_last_id, size);
   legacy_report("add_block_sums_wrapper");
+}
+
+// The four launch helpers the reference library also exports (fsw_embedding.cu:125-183; nothing in the reference's Python
+// binds them): same kernels, default stream, no synchronisation -- exactly the reference's behaviour.
+extern "C" void launch_segcumsum_kernel_float(float* values, const int64_t* segment_ids, int64_t size, int64_t max_seg_size,
+                                              float* block_sums_out, int64_t* block_last_ids_out, bool return_next_level,
+                                              int64_t num_blocks, int64_t threads_per_block, int64_t shared_memory_size) {
+  (void)max_seg_size;
+  (void)shared_memory_size;
+  if (size <= 0 || num_blocks <= 0 || threads_per_block <= 0 || threads_per_block > 1024) return;
+  k_legacy_block_scan<float><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(values, segment_ids, size, block_sums_out,
+                                                                                             block_last_ids_out, return_next_level);
+}
+extern "C" void launch_segcumsum_kernel_double(double* values, const int64_t* segment_ids, int64_t size, int64_t max_seg_size,
+                                               double* block_sums_out, int64_t* block_last_ids_out, bool return_next_level,
+                                               int64_t num_blocks, int64_t threads_per_block, int64_t shared_memory_size) {
+  (void)max_seg_size;
+  (void)shared_memory_size;
+  if (size <= 0 || num_blocks <= 0 || threads_per_block <= 0 || threads_per_block > 1024) return;
+  k_legacy_block_scan<double><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(values, segment_ids, size, block_sums_out,
+                                                                                              block_last_ids_out, return_next_level);
+}
+extern "C" void launch_add_block_sums_kernel_float(float* output, const float* block_sums, const int64_t* segment_ids,
+                                                   const int64_t* block_last_id, int64_t size, int64_t num_blocks,
+                                                   int64_t threads_per_block) {
+  if (size <= 0 || num_blocks <= 0 || threads_per_block <= 0 || threads_per_block > 1024) return;
+  k_legacy_add_block_sums<float><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(output, block_sums, segment_ids,
+                                                                                                 block_last_id, size);
+}
+extern "C" void launch_add_block_sums_kernel_double(double* output, const double* block_sums, const int64_t* segment_ids,
+                                                    const int64_t* block_last_id, int64_t size, int64_t num_blocks,
+                                                    int64_t threads_per_block) {
+  if (size <= 0 || num_blocks <= 0 || threads_per_block <= 0 || threads_per_block > 1024) return;
+  k_legacy_add_block_sums<double><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(output, block_sums, segment_ids,
+                                                                                                  block_last_id, size);
 }
 
 extern "C" int get_max_threads_per_block(int device_index) {

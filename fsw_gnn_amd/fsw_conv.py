@@ -255,7 +255,10 @@ class FSW_conv(_Base):
             return self._tail(emb, vertex_features)
 
         prepared = None
-        if self._fusable():
+        # The fused kernel needs every row within the register path, which only the stats read inside prepare() tells.  The
+        # projection is launched before that read (so the host round trip hides under it) on the assumption that this graph
+        # looks like the previous one: after a graph with long rows the x . W2^T block is not computed speculatively.
+        if self._fusable() and not getattr(self, '_saw_long_rows', False):
             # fast path: the projection GEMM also produces x . W2^T + b, then ONE kernel does the neighbourhood
             # embedding and E . W1^T (+ activation); the embedding never reaches HBM (csrc/conv_fused.hip)
             lin = self.mlp[0]
@@ -270,6 +273,7 @@ class FSW_conv(_Base):
                 for m in self.mlp[next_module:]:
                     y = m(y)
                 return y
+            self._saw_long_rows = True
 
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
@@ -280,6 +284,9 @@ class FSW_conv(_Base):
                 xc.copy_(x)
         else:
             emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)   # X stored by the projection kernel
+            if self._fusable():
+                st = graph.stats()
+                self._saw_long_rows = st[_lib.STAT_NUM_LDS] > 0 or st[_lib.STAT_NUM_GLOBAL] > 0
         return self._tail_buffer(buf)
 
     def _tail(self, emb, vertex_features):

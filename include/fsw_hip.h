@@ -247,8 +247,8 @@ int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int6
 
 /* ---- stand-alone segmented cumulative sum --------------------------------------------------------
  * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of
- * values restarted wherever consecutive segment ids differ, single pass (decoupled look-back),
- * in place allowed (out == values).  value_dtype: 0 float32, 1 float64 (the reference's torch_dtype
+ * values restarted wherever consecutive segment ids differ, ONE streaming pass (chained scan with decoupled
+ * look-back: every element read once and written once), in place allowed (out == values).  value_dtype: 0 float32, 1 float64 (the reference's torch_dtype
  * enum, fsw_embedding.cu:14-17).  id_bytes: 4 or 8.  reverse != 0 scans from the end (the backward
  * pass of cumsum_sparse, fsw_embedding.py:2158-2172).  workspace: fsw_segcumsum_workspace_bytes(n). */
 size_t fsw_segcumsum_workspace_bytes(int64_t n);
@@ -264,6 +264,18 @@ void segcumsum_wrapper(int dtype, void* values, const int64_t* segment_ids, int6
 void add_block_sums_wrapper(int dtype, void* output, const void* block_sums, const int64_t* segment_ids,
                             const int64_t* block_last_id, int64_t size, int64_t num_blocks, int64_t threads_per_block);
 int get_max_threads_per_block(int device_index);
+/* the launch helpers the reference library exports next to its wrappers (fsw_embedding.cu:125-183): default stream, no
+ * synchronisation, void return */
+void launch_segcumsum_kernel_float(float* values, const int64_t* segment_ids, int64_t size, int64_t max_seg_size,
+                                   float* block_sums_out, int64_t* block_last_ids_out, bool return_next_level,
+                                   int64_t num_blocks, int64_t threads_per_block, int64_t shared_memory_size);
+void launch_segcumsum_kernel_double(double* values, const int64_t* segment_ids, int64_t size, int64_t max_seg_size,
+                                    double* block_sums_out, int64_t* block_last_ids_out, bool return_next_level,
+                                    int64_t num_blocks, int64_t threads_per_block, int64_t shared_memory_size);
+void launch_add_block_sums_kernel_float(float* output, const float* block_sums, const int64_t* segment_ids,
+                                        const int64_t* block_last_id, int64_t size, int64_t num_blocks, int64_t threads_per_block);
+void launch_add_block_sums_kernel_double(double* output, const double* block_sums, const int64_t* segment_ids,
+                                         const int64_t* block_last_id, int64_t size, int64_t num_blocks, int64_t threads_per_block);
 
 #ifdef __cplusplus
 }

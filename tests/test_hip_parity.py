@@ -645,6 +645,45 @@ def test_segcumsum_large_random(dev):
     assert relerr(got, O.segcumsum(vals, ids)) < 1e-13
 
 
+@pytest.mark.parametrize("case", ["short", "one_segment", "long_runs", "all_heads"])
+def test_segcumsum_chained_scan_cases(dev, case):
+    """The single-pass chained scan across many tiles: segment structures that end the look-back at once (short
+    segments), never (one segment: every tile waits for a published prefix) and in between; sizes that are and are not
+    multiples of the vector width / tile, forward and reverse, both id widths, in place, unaligned views."""
+    from fsw_gnn_amd import segcumsum
+    rng = np.random.default_rng({"short": 1, "one_segment": 2, "long_runs": 3, "all_heads": 4}[case])
+    for n in (1, 7, 4096, 4097, 1_000_003, 2_500_000):
+        if case == "short":
+            ids = np.cumsum(rng.random(n) < 0.12)
+        elif case == "one_segment":
+            ids = np.zeros(n, dtype=np.int64)
+        elif case == "long_runs":
+            ids = np.cumsum(rng.random(n) < 1.0 / 30000.0)
+        else:
+            ids = np.arange(n)
+        ids = ids.astype(np.int64)
+        vals = rng.standard_normal(n)
+        ref = O.segcumsum(vals, ids)
+        refr = O.segcumsum(vals[::-1].copy(), ids[::-1].copy())[::-1]
+        scale = np.abs(ref).max() + 1e-300
+        for vdt, tol in ((torch.float64, 1e-12), (torch.float32, 3e-5)):      # float32: sums of up to 2.5M terms
+            v = t(vals, dev, vdt)
+            for idt in (torch.int64, torch.int32):
+                i = t(ids, dev, idt)
+                assert np.abs(segcumsum(v, i).cpu().numpy() - ref).max() / scale < tol, (case, n, vdt, idt)
+                assert np.abs(segcumsum(v, i, reverse=True).cpu().numpy() - refr).max() / scale < tol, (case, n, vdt, idt, "rev")
+        # unaligned views (scalar path) and in place
+        vp = torch.zeros(n + 3, device=dev, dtype=torch.float32)
+        vp[3:] = t(vals, dev)
+        ip = torch.zeros(n + 1, device=dev, dtype=torch.int64)
+        ip[1:] = t(ids, dev, torch.int64)
+        got = segcumsum(vp[3:], ip[1:])
+        assert np.abs(got.cpu().numpy() - ref).max() / scale < 3e-5
+        w = t(vals, dev, torch.float64)
+        assert segcumsum(w, t(ids, dev, torch.int64), in_place=True).data_ptr() == w.data_ptr()
+        assert np.abs(w.cpu().numpy() - ref).max() / scale < 1e-12
+
+
 def test_legacy_abi_drives_reference_hierarchy(dev):
     """segcumsum_wrapper / add_block_sums_wrapper with the reference's driver loop (fsw_embedding.py:2905-3010)."""
     import ctypes
