@@ -42,6 +42,17 @@ class EmbedArgs(ctypes.Structure):
     ]
 
 
+class GenericArgs(ctypes.Structure):
+    """struct fsw_generic_args of include/fsw_hip.h (field order and types must match)."""
+    _fields_ = [
+        ("value_dtype", c_i32), ("S", c_i32), ("rowptr", c_vp), ("col", c_vp), ("w", c_vp), ("num_rows", c_i64),
+        ("max_degree", c_i64), ("Xp", c_vp), ("ldp", c_i64), ("Ke", c_vp), ("ldke", c_i64), ("freqs", c_vp),
+        ("tau", ctypes.c_double), ("out", c_vp), ("ldo", c_i64), ("bias", c_vp), ("out_scale", ctypes.c_double),
+        ("has_mass", c_i32), ("mass_fn", c_i32), ("mass_scale", ctypes.c_double), ("g", c_vp), ("ldg", c_i64),
+        ("gkey", c_vp), ("ldk", c_i64), ("gfreq", c_vp), ("gw", c_vp), ("scratch", c_vp), ("scratch_bytes", c_sz),
+    ]
+
+
 _SIGNATURES = {
     "fsw_abi_version": (ctypes.c_int, []),
     "fsw_arch": (ctypes.c_char_p, []),
@@ -65,6 +76,9 @@ _SIGNATURES = {
     "fsw_unit_dcoeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_backward_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_embed_backward_keys_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_embed_generic_scratch_bytes": (c_sz, [c_i64, c_i64]),
+    "fsw_embed_generic": (ctypes.c_int, [ctypes.POINTER(GenericArgs), c_vp]),
+    "fsw_project_f64": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "fsw_segcumsum_workspace_bytes": (c_sz, [c_i64]),
     "fsw_segcumsum": (ctypes.c_int, [ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_sz, c_vp]),
     # legacy ABI, exact reference signatures (reference fsw_embedding.py:2952-2977)

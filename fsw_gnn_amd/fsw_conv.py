@@ -236,6 +236,12 @@ class FSW_conv(_Base):
         n = vertex_features.size(0)
         if n == 0:
             return torch.zeros((0, self.out_channels), dtype=vertex_features.dtype, device=vertex_features.device)
+        if emb_mod.get_dtype() == torch.float64:
+            # float64 build (the reference's test_conv.py runs the layer this way): the reference's own structure -- coalesced
+            # COO adjacency and edge features (fsw_conv.py:384-447), FSW_embedding.forward on the generic kernels, torch tail
+            adj, x_edge = self.adjacency_coo(edge_index, edge_features if self.edgefeat_dim > 0 else None, n, vertex_features.dtype)
+            emb = emb_mod(vertex_features, W=adj, X_edge=x_edge, graph_mode=True)
+            return self._tail(emb, vertex_features)
         x = vertex_features.contiguous()
         if getattr(self, '_node_parallel', False):
             if needs_grad:
@@ -288,6 +294,33 @@ class FSW_conv(_Base):
                 st = graph.stats()
                 self._saw_long_rows = st[_lib.STAT_NUM_LDS] > 0 or st[_lib.STAT_NUM_GLOBAL] > 0
         return self._tail_buffer(buf)
+
+    def adjacency_coo(self, edge_index, edge_features, num_vertices, dtype):
+        """Coalesced COO adjacency adj[recipient, sender] and edge-feature tensor exactly as the reference builds them
+        (FSW_conv.edge_index_to_adj, fsw_conv.py:384-447): parallel edges summed, optional self loops, 'gcn' weighting by the
+        weighted in-degrees; differentiable in edge_features (torch's coalesce)."""
+        dev = edge_index.device
+        inds = edge_index.flip(0)
+        vals = torch.ones(edge_index.shape[1], device=dev, dtype=dtype)
+        if self.self_loop_weight > 0:
+            loops = torch.arange(num_vertices, device=dev).reshape(1, num_vertices).repeat(2, 1)
+            inds = torch.cat((inds, loops), dim=1)
+            vals = torch.cat((vals, self.self_loop_weight * torch.ones(num_vertices, device=dev, dtype=dtype)), dim=0)
+        adj = torch.sparse_coo_tensor(indices=inds, values=vals, size=(num_vertices, num_vertices)).coalesce()
+        if self.edge_weighting == 'gcn':
+            ai, av = adj.indices(), adj.values()
+            ds = torch.sqrt(torch.zeros(num_vertices, device=dev, dtype=dtype).index_add_(0, ai[0], av))
+            adj = torch.sparse_coo_tensor(ai, av / ds[ai[0]] / ds[ai[1]], adj.shape, is_coalesced=True)
+        x_edge = None
+        if edge_features is not None:
+            ef = edge_features
+            if self.self_loop_weight > 0:
+                shape = list(ef.shape)
+                shape[0] = num_vertices
+                ef = torch.cat((ef, torch.zeros(shape, device=dev, dtype=dtype)), dim=0)
+            size = tuple(adj.shape) if ef.dim() == 1 else tuple(adj.shape) + (self.edgefeat_dim,)
+            x_edge = torch.sparse_coo_tensor(indices=inds, values=ef, size=size).coalesce()
+        return adj, x_edge
 
     def _tail(self, emb, vertex_features):
         """concat with the vertex features, MLP / dim_reduct, final BatchNorm through torch autograd (fsw_conv.py:357-369)."""
@@ -530,6 +563,14 @@ class FSW_readout(FSW_conv):
         src = torch.arange(num_vertices, device=vertex_features.device, dtype=torch.int64)
         if batch_size == 0 or num_vertices == 0:
             return torch.zeros((batch_size, self.out_channels), dtype=vertex_features.dtype, device=vertex_features.device)
+        if emb_mod.get_dtype() == torch.float64:   # float64 build: the reference's adjacency [graph_index, arange] (fsw_conv.py:503-515)
+            assert int(graph_index.min()) >= 0 and int(graph_index.max()) < batch_size, 'all entries of graph_index must be in the range 0,...,batch_size-1'
+            adj = torch.sparse_coo_tensor(torch.stack((graph_index, src)), torch.ones(num_vertices, dtype=torch.float64, device=src.device),
+                                          size=(batch_size, num_vertices)).coalesce()
+            emb = emb_mod(vertex_features, W=adj, graph_mode=True)
+            if self.mlp is not None:
+                return self.mlp(emb)
+            return torch.matmul(emb, self.dim_reduct.transpose(0, 1)) if self.concat_self else emb
         graph = build_csr(graph_index.contiguous(), src, None, batch_size, num_vertices)
         needs_grad = torch.is_grad_enabled() and (vertex_features.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:

@@ -12,7 +12,8 @@ Autograd: forward under grad mode goes through _EmbedGraphFn (HIP backward kerne
 csrc/embed_wsort_bwd.hip) for every weight mode and degree class; gradients flow to X, projVecs, freqs, bias and the
 total-mass scale (the weights W are constants).
 Edge features (d_edge > 0) go through the coalescing CSR build and the general-weight kernels.
-Not implemented (raise NotImplementedError): Cartesian mode (nSlices x nFreqs), gradients w.r.t. W.
+dtype=torch.float64 modules and gradients w.r.t. the weights W / sparse edge features run on the generic kernels
+(csrc/embed_generic.hip: any degree, float64 arithmetic).  Not implemented (raise NotImplementedError): Cartesian mode.
 """
 import ctypes
 import numbers
@@ -181,6 +182,151 @@ def dist_rank(group):
     return dist.get_rank(group)
 
 
+class SimpleCSR:
+    """Plain CSR adjacency for the generic kernels (csrc/embed_generic.hip): rowptr int32 [num_rows + 1], col int32 [nnz] with
+    the entries in the order of the coalesced COO tensor they came from (row-major), max_degree on the host."""
+
+    def __init__(self, rec, snd, num_rows, num_cols):
+        dev = rec.device
+        counts = torch.bincount(rec, minlength=num_rows) if rec.numel() else torch.zeros(num_rows, dtype=torch.int64, device=dev)
+        self.rowptr = torch.zeros(num_rows + 1, dtype=torch.int32, device=dev)
+        self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.col = snd.to(torch.int32).contiguous()
+        self.rec = rec
+        self.num_rows, self.num_cols, self.nnz = num_rows, num_cols, int(rec.numel())
+        self.max_degree = int(counts.max()) if num_rows > 0 and rec.numel() else 0
+        if fsw_embedding_basic_safety_checks and rec.numel():
+            assert bool((rec[1:] >= rec[:-1]).all()), 'adjacency entries must be sorted by recipient (coalesced COO order)'
+            assert int(snd.min()) >= 0 and int(snd.max()) < num_cols and int(rec.min()) >= 0 and int(rec.max()) < num_rows, \
+                "adjacency index out of range"
+
+
+def _generic_args(module, csr, Xp, ldp, Ke, freqs, wvals, out_scale, has_mass, mass_scale, scratch):
+    a = _lib.GenericArgs()
+    a.value_dtype = 1 if Xp.dtype == torch.float64 else 0
+    a.S = freqs.numel()
+    a.rowptr, a.col = csr.rowptr.data_ptr(), csr.col.data_ptr() if csr.nnz else None
+    a.w = wvals.data_ptr() if wvals is not None else None
+    a.num_rows, a.max_degree = csr.num_rows, csr.max_degree
+    a.Xp, a.ldp = Xp.data_ptr(), ldp
+    a.Ke, a.ldke = (Ke.data_ptr(), Ke.stride(0)) if Ke is not None else (None, 0)
+    a.freqs, a.tau = freqs.data_ptr(), float(module.total_mass_pad_thresh)
+    a.out_scale, a.has_mass = float(out_scale), has_mass
+    a.mass_fn, a.mass_scale = _MASS_FN[module.total_mass_encoding_function], float(mass_scale)
+    a.scratch, a.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    return a
+
+
+class _GenericEmbedFn(torch.autograd.Function):
+    """out = out_scale * E(X, W) through the generic kernels (csrc/embed_generic.hip: any degree, float32 or float64 storage,
+    float64 arithmetic) with gradients for X, projVecs, freqs, bias, the total-mass scale, the WEIGHTS and the edge features.
+
+    Two callers: every float64 module (the float64 build of the path, reference test_conv.py:24), and float32 modules whose
+    weights require a gradient (the tuned float32 backward kernels treat W as a constant).  Replaces the reference's sparse
+    autograd chain incl. ag.div_sparse_dense.backward (fsw_embedding.py:1656), ag.cumsum_sparse.backward (:2160, the reverse
+    segmented cumsum) and ag.permute_sparse.backward (:1286)."""
+
+    @staticmethod
+    def forward(ctx, X, V, freqs, bias, mass_scale, wvals, efvals, module, csr, out_scale):
+        L = _lib.lib()
+        dev, dt = X.device, X.dtype
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        S, d_in = module.nSlices, module.d_in
+        has_mass = 1 if module.encode_total_mass else 0
+        with torch.no_grad():
+            Xc, Vd, fr = X.detach().contiguous(), V.detach(), freqs.detach().contiguous()
+            ldp = _round_up(S, 64)
+            Xp = torch.empty((Xc.shape[0], ldp), dtype=dt, device=dev)
+            if dt == torch.float64:
+                _lib.check(L.fsw_project_f64(_lib.ptr(Xc), Xc.shape[0], d_in, Xc.stride(0), _lib.ptr(Vd), S, Vd.stride(0), _lib.ptr(Xp), ldp,
+                                             None, stream), "fsw_project_f64")
+            else:
+                _lib.check(L.fsw_project_f32(_lib.ptr(Xc), Xc.shape[0], d_in, Xc.stride(0), _lib.ptr(Vd), S, Vd.stride(0), _lib.ptr(Xp), ldp,
+                                             None, 0, None, stream), "fsw_project_f32")
+            Ke = None
+            if efvals is not None:
+                Ke = (efvals.detach() @ Vd[:, d_in:].t()).contiguous()        # [nnz, S], the reference's E x S edge term (:934-968)
+            wv = wvals.detach().contiguous() if wvals is not None else None
+            scratch = torch.empty(int(L.fsw_embed_generic_scratch_bytes(csr.max_degree, max(csr.num_rows, 1))), dtype=torch.uint8, device=dev)
+            out = torch.empty((csr.num_rows, has_mass + S), dtype=dt, device=dev)
+            ms = float(mass_scale.detach()) if mass_scale is not None else 1.0
+            a = _generic_args(module, csr, Xp, ldp, Ke, fr, wv, out_scale, has_mass, ms, scratch)
+            a.out, a.ldo = out.data_ptr(), out.stride(0)
+            b = bias.detach().contiguous() if bias is not None else None
+            a.bias = b.data_ptr() if b is not None else None
+            _lib.check(L.fsw_embed_generic(ctypes.byref(a), stream), "fsw_embed_generic")
+        ctx.module, ctx.csr, ctx.out_scale, ctx.mass_scale_value = module, csr, float(out_scale), ms
+        ctx.aux = (Xp, ldp, Ke, wv)
+        ctx.has_ef, ctx.has_w = efvals is not None, wvals is not None
+        ctx.save_for_backward(X, V, freqs, efvals if efvals is not None else X.new_zeros(0))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        L = _lib.lib()
+        module, csr, out_scale = ctx.module, ctx.csr, ctx.out_scale
+        X, V, freqs, efvals = ctx.saved_tensors
+        Xp, ldp, Ke, wv = ctx.aux
+        dev, dt = X.device, X.dtype
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        S, d_in = module.nSlices, module.d_in
+        has_mass = 1 if module.encode_total_mass else 0
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        gX = gV = gfreqs = gbias = gscale = gW = gEf = None
+        nnz = csr.nnz
+        want_key = need[0] or need[1] or (ctx.has_ef and need[6])
+        want_w = ctx.has_w and need[5]
+        if nnz and S and (want_key or need[2] or want_w):
+            gkey = torch.zeros((nnz, S), dtype=dt, device=dev) if want_key else None
+            gf = torch.zeros(S, dtype=dt, device=dev) if need[2] else None
+            gw = torch.zeros(nnz, dtype=dt, device=dev) if want_w else None
+            scratch = torch.empty(int(L.fsw_embed_generic_scratch_bytes(csr.max_degree, max(csr.num_rows, 1))), dtype=torch.uint8, device=dev)
+            a = _generic_args(module, csr, Xp, ldp, Ke, freqs.detach().contiguous(), wv, out_scale, has_mass, ctx.mass_scale_value, scratch)
+            a.g, a.ldg = g.data_ptr(), g.stride(0)
+            a.gkey, a.ldk = (gkey.data_ptr(), S) if gkey is not None else (None, 0)
+            a.gfreq = gf.data_ptr() if gf is not None else None
+            a.gw = gw.data_ptr() if gw is not None else None
+            _lib.check(L.fsw_embed_generic(ctypes.byref(a), stream), "fsw_embed_generic (backward)")
+            Vd = V.detach()
+            if need[0] or need[1]:
+                gXp = torch.zeros((X.shape[0], S), dtype=dt, device=dev).index_add_(0, csr.col.long(), gkey)
+                if need[0]:
+                    gX = gXp @ Vd[:, :d_in]
+                if need[1]:
+                    gV = gXp.t() @ X.detach()
+                    if ctx.has_ef:
+                        gV = torch.cat([gV, gkey.t() @ efvals.detach()], dim=1)
+            if ctx.has_ef and need[6]:
+                gEf = gkey @ Vd[:, d_in:]
+            gfreqs, gW = gf, gw
+        if need[0] and gX is None:
+            gX = torch.zeros_like(X)
+        if need[1] and gV is None:
+            gV = torch.zeros_like(V)
+        if need[2] and gfreqs is None:
+            gfreqs = torch.zeros_like(freqs)
+        if ctx.has_ef and need[6] and gEf is None:
+            gEf = torch.zeros_like(efvals)
+        if need[3]:
+            gbias = out_scale * g.sum(dim=0)
+        if has_mass and (need[4] or want_w):
+            m = torch.zeros(csr.num_rows, dtype=dt, device=dev)
+            if nnz:
+                m.index_add_(0, csr.rec, wv if wv is not None else torch.ones(nnz, dtype=dt, device=dev))
+            fn = module.total_mass_encoding_function
+            if need[4]:
+                fm = m if fn == 'identity' else (2 * (m / (torch.sqrt(m + 1) + 1)) if fn == 'sqrt' else torch.log1p(m))
+                gscale = (out_scale * (g[:, 0] * fm).sum()).reshape(())
+            if want_w:      # the total-mass column depends on the weights through m
+                dfm = torch.ones_like(m) if fn == 'identity' else (1 / torch.sqrt(m + 1) if fn == 'sqrt' else 1 / (1 + m))
+                gW = (gW if gW is not None else torch.zeros(nnz, dtype=dt, device=dev)) + (out_scale * ctx.mass_scale_value * g[:, 0] * dfm)[csr.rec]
+        if want_w and gW is None:
+            gW = torch.zeros(nnz, dtype=dt, device=dev)
+        return gX, gV, gfreqs, gbias, gscale, gW, gEf, None, None, None
+
+
 class FSW_embedding(nn.Module):
     def __init__(self,
                  d_in, d_out=None, nSlices=None, nFreqs=None, collapse_freqs=False,
@@ -251,8 +397,8 @@ class FSW_embedding(nn.Module):
         self.device_new = torch.device(device)
         assert dtype.is_floating_point and (not dtype.is_complex), \
             'dtype must be real floating-point; instead got dtype=%s' % (dtype)
-        if dtype != torch.float32:
-            raise NotImplementedError("fsw_gnn_amd: the HIP kernels compute in float32 (got dtype=%s)" % dtype)
+        if dtype not in (torch.float32, torch.float64):
+            raise NotImplementedError("fsw_gnn_amd: the HIP kernels are built for float32 and float64 (got dtype=%s)" % dtype)
         self.dtype_new = dtype
         self.report = report
         self.report_on_coherence_minimization = report_on_coherence_minimization
@@ -376,8 +522,6 @@ class FSW_embedding(nn.Module):
             assert torch.is_tensor(W), 'When X_edge is provided, W must be provided explicitly'
             assert X_edge.device == self.get_device() and X_edge.dtype == self.get_dtype(), 'X_edge has the wrong device or dtype'
             assert X_edge.is_sparse == W.is_sparse, 'X_edge and W must either both or neither be sparse'
-            if torch.is_grad_enabled() and X_edge.requires_grad:
-                raise NotImplementedError("fsw_gnn_amd: gradients w.r.t. X_edge are provided through FSW_conv(edge_features=...) only")
         else:
             assert (X_edge is None) or (X_edge.numel() == 0), 'X_edge should be None or empty since d_edge == 0'
         assert torch.is_tensor(X), 'X must be a pytorch tensor. Instead got type %s' % (type(X))
@@ -387,8 +531,10 @@ class FSW_embedding(nn.Module):
         if X.device.type != 'cuda':
             raise RuntimeError("fsw_gnn_amd: forward needs tensors on a HIP device ('cuda'); there is no CPU path")
         needs_grad = torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if torch.is_grad_enabled() and torch.is_tensor(W) and W.requires_grad:
-            raise NotImplementedError("fsw_gnn_amd: gradients with respect to the weights W are not implemented")
+        # float64 modules, and float32 calls that ask for gradients of the weights or of sparse edge features, run on the
+        # generic kernels (csrc/embed_generic.hip); everything else on the tuned float32 kernels
+        generic = self.get_dtype() == torch.float64 or (torch.is_grad_enabled() and (
+            (torch.is_tensor(W) and W.requires_grad) or (X_edge is not None and torch.is_tensor(X_edge) and X_edge.requires_grad)))
         if torch.is_tensor(W):
             assert W.dtype == self.get_dtype(), ("W has the wrong dtype. Expected %s, got %s" % (self.get_dtype(), W.dtype))
             assert W.device == self.get_device(), ("W is on the wrong device. Expected %s, got %s" % (self.get_device(), W.device))
@@ -401,6 +547,7 @@ class FSW_embedding(nn.Module):
         assert X.shape[-1] == self.d_in, "The last dimension of X must equal d_in=%d. Instead got %d" % (self.d_in, X.shape[-1])
 
         d = self.d_in
+        efvals = None
         if not graph_mode:
             batch_dims = tuple(X.shape[0:-2])
             n = X.shape[-2]
@@ -462,6 +609,10 @@ class FSW_embedding(nn.Module):
             Xf = X.reshape(B * n, d)
             num_rows, out_shape = B * nR, batch_dims + (nR,)
 
+        if generic and num_rows > 0 and Xf.shape[0] > 0:
+            if self.d_out == 0:
+                return torch.zeros(out_shape + (0,), dtype=X.dtype, device=X.device)
+            return self._forward_generic(Xf.contiguous(), rec, snd, wvals, efvals, num_rows).reshape(out_shape + (self.d_out,))
         if num_rows == 0 or Xf.shape[0] == 0:
             # nothing to embed / empty multisets only: the reference returns an empty tensor, resp. the embedding of the
             # pad element alone; the kernels need at least one row and one point
@@ -478,6 +629,36 @@ class FSW_embedding(nn.Module):
             out = torch.empty((num_rows, self.d_out), dtype=X.dtype, device=X.device)
             self.embed_into(Xf, graph, out, out_scale=1.0, serialize_num_slices=serialize_num_slices)
         return out.reshape(out_shape + (self.d_out,))
+
+    def _forward_generic(self, Xf, rec, snd, wvals, efvals, num_rows):
+        """The generic-kernel path (float64 modules; float32 with gradients of W / X_edge): differentiable in everything."""
+        if self.nSlices == 0:
+            raise NotImplementedError("fsw_gnn_amd: nSlices == 0 with encode_total_mass is not supported")
+        if fsw_embedding_basic_safety_checks:      # reference fsw_embedding.py:652-703
+            assert bool(torch.isfinite(Xf).all()), "The entries of X cannot contain NaNs or infs"
+            if wvals is not None:
+                assert bool(torch.isfinite(wvals).all()), "All entries of W must be finite"
+                assert bool((wvals >= 0).all()), "All entries of W must be nonnegative"
+        csr = SimpleCSR(rec, snd, num_rows, Xf.shape[0])
+        bias = self.bias if self.enable_bias else None
+        scale = self.total_mass_encoding_scale if self.encode_total_mass else None
+        plain = (not self.encode_total_mass) or self.total_mass_encoding_method == 'plain'
+        P = _GenericEmbedFn.apply(Xf, self.projVecs, self.freqs, bias if plain else None, scale, wvals, efvals, self, csr, 1.0)
+        return P if plain else self._homog_epilogue(P, 1.0, bias)
+
+    def _homog_epilogue(self, P, out_scale, bias):
+        """'homog' / 'homog_alt' (reference fsw_embedding.py:874-882, 1136-1144) on the 'plain' embedding P = [f(m) scale | emb]
+        without bias, out of place so that autograd differentiates it."""
+        tm = P[:, 0:1] / out_scale
+        emb = P[:, 1:]
+        norm = emb.abs().mean(dim=-1, keepdim=True) / out_scale
+        if self.total_mass_encoding_method == 'homog':
+            col0 = out_scale * tm * norm
+        else:
+            col0 = out_scale * torch.where(tm <= 1, tm * (2 - tm), torch.ones_like(tm)) * norm
+            emb = emb * torch.where(tm <= 1, tm.square(), 2 * tm - 1)
+        out = torch.cat([col0, emb], dim=1)
+        return out + out_scale * bias if bias is not None else out
 
     def embed_autograd(self, X, graph, out_scale=1.0, edge_feat=None, slice_range=None, group=None, reduce_grads=False):
         """Differentiable embedding of a CSR graph (training path): see _EmbedGraphFn.  edge_feat: the per-input-edge
@@ -497,16 +678,7 @@ class FSW_embedding(nn.Module):
             P = _EmbedGraphFn.apply(X, self.projVecs, self.freqs, None, scale, edge_feat, self, graph, out_scale, None, None, False)
         finally:
             self._force_plain = False
-        tm = P[:, 0:1] / out_scale
-        emb = P[:, 1:]
-        norm = emb.abs().mean(dim=-1, keepdim=True) / out_scale
-        if self.total_mass_encoding_method == 'homog':
-            col0 = out_scale * tm * norm
-        else:
-            col0 = out_scale * torch.where(tm <= 1, tm * (2 - tm), torch.ones_like(tm)) * norm
-            emb = emb * torch.where(tm <= 1, tm.square(), 2 * tm - 1)
-        out = torch.cat([col0, emb], dim=1)
-        return out + out_scale * bias if bias is not None else out
+        return self._homog_epilogue(P, out_scale, bias)
 
     # ------------------------------------------------------------------------------------------------
     _force_plain = False   # embed_autograd: 'plain' mass column and no bias from the kernels, epilogue in torch

@@ -245,6 +245,62 @@ int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, cons
 int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int64_t ldg, float* gkey, int64_t ldk,
                                 float* gfreq, fsw_stream_t stream);
 
+/* ---- generic neighbourhood kernels: any in-degree, float32 or float64 storage, float64 arithmetic ------------------------
+ * (csrc/embed_generic.hip)  Two uses:
+ *   value_dtype 1 (float64): the float64 build of the path -- FSW_embedding / FSW_conv(dtype=torch.float64), which the
+ *       reference's own test_conv.py runs (test_conv.py:24); forward (g == NULL) and backward (g != NULL);
+ *   value_dtype 0 (float32): gradients with respect to the weights for the float32 path (gw), which the tuned backward
+ *       kernels above treat as constants (reference ag.div_sparse_dense.backward fsw_embedding.py:1656,
+ *       ag.cumsum_sparse.backward :2160, ag.permute_sparse.backward :1286).
+ * The graph is a plain CSR (rowptr / col / w in CSR order, no degree bins).  All value pointers have the type selected by
+ * value_dtype.  Ke (nullable): the edge-feature term of every key, Ke[e * ldke + k] = <efeat_e, projVecs[k, d_in:]>
+ * (reference fsw_embedding.py:934-968), added to Xp[col[e], k].
+ * Forward:  out[r * ldo + has_mass + k] = out_scale * ((1 + xi_k) sum_t Delta_t p_(t) + bias[has_mass + k]), and with has_mass
+ *           out[r * ldo] = out_scale * (f(m_r) * mass_scale + bias[0]).
+ * Backward: for the output gradient g [num_rows, ldg] (column has_mass + k belongs to slice k)
+ *           gkey[e * ldk + k]  = out_scale * g[r, k] * d out[r, k] / d key_e              (stored; nullable)
+ *           gfreq[k]          += out_scale * sum_r g[r, k] * d out[r, k] / d xi_k          (accumulated; nullable)
+ *           gw[e]             += out_scale * sum_k g[r, k] * d out[r, k] / d w_e           (accumulated; nullable; the
+ *                                total-mass column's dependence on w is NOT included).
+ * scratch: fsw_embed_generic_scratch_bytes(max_degree, num_rows) bytes.                                                */
+typedef struct {
+  int32_t value_dtype;   /* 0 float32, 1 float64 */
+  int32_t S;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const void* w;         /* [nnz] raw weights, NULL = unit */
+  int64_t num_rows;
+  int64_t max_degree;    /* host value: an upper bound of the longest row */
+  const void* Xp;
+  int64_t ldp;
+  const void* Ke;
+  int64_t ldke;
+  const void* freqs;
+  double tau;
+  void* out;
+  int64_t ldo;
+  const void* bias;
+  double out_scale;
+  int32_t has_mass;
+  int32_t mass_fn;
+  double mass_scale;
+  const void* g;
+  int64_t ldg;
+  void* gkey;
+  int64_t ldk;
+  void* gfreq;
+  void* gw;
+  void* scratch;
+  size_t scratch_bytes;
+} fsw_generic_args;
+
+size_t fsw_embed_generic_scratch_bytes(int64_t max_degree, int64_t num_rows);
+int fsw_embed_generic(const fsw_generic_args* args, fsw_stream_t stream);
+/* Xp [n, ldp] = X [n, ldx] . V [S, ldv]^T in float64 on the matrix cores (v_mfma_f64_16x16x4_f64); sets
+ * FSW_FLAG_X_NONFINITE in stats[FSW_STAT_FLAGS] (stats nullable) */
+int fsw_project_f64(const double* X, int64_t n, int d, int64_t ldx, const double* V, int S, int64_t ldv, double* Xp,
+                    int64_t ldp, int32_t* stats, fsw_stream_t stream);
+
 /* ---- stand-alone segmented cumulative sum --------------------------------------------------------
  * Replaces segcumsum / segcumsum_cuda (reference fsw_embedding.py:2795-3012): inclusive scan of
  * values restarted wherever consecutive segment ids differ, ONE streaming pass (chained scan with decoupled

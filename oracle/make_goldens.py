@@ -261,6 +261,76 @@ def case_grads_homog(emb, conv):
     save("grads_homog", **arrays)
 
 
+def case_grads_w(emb, conv):
+    """Gradients with respect to the WEIGHTS from the reference's autograd (ag.div_sparse_dense.backward fsw_embedding.py:1656,
+    ag.cumsum_sparse.backward :2160, ag.permute_sparse.backward :1286, custom_lowclamp :1735): tiny graph with sparse weights
+    (rows on both sides of the pad threshold), tau = 1 and tau = 3, and a dense batch of weighted point clouds."""
+    g = np.load(os.path.join(GOLD, "tiny_graph.npz"))
+    gt = np.load(os.path.join(GOLD, "grads_tiny.npz"))
+    dt = torch.float64
+    n, d, S = 64, 8, 16
+    X0, V, fr, bias, ei, R = g["X"], g["V"], gt["freqs"], g["bias"], g["edge_index"], gt["R"]
+    adj, _, _ = conv.FSW_conv.edge_index_to_adj(torch.from_numpy(ei), None, n, 0, dt)
+    arrays = {}
+    for tag, tau, fn in (("tau1", 1.0, "identity"), ("tau3", 3.0, "log")):
+        Em = emb.FSW_embedding(d_in=d, d_out=S + 1, encode_total_mass=True, total_mass_encoding_scale=0.7, total_mass_encoding_function=fn,
+                               total_mass_pad_thresh=tau, learnable_slices=True, learnable_freqs=True, device="cpu", dtype=dt,
+                               load_custom_cuda_lib=False)
+        set_params(Em, V, fr, bias=bias, scale=0.7)
+        vals = torch.from_numpy(g["adj3_values"].copy()).requires_grad_(True)
+        A = torch.sparse_coo_tensor(adj.indices(), vals, adj.shape, is_coalesced=True)
+        X = T(X0, dt).requires_grad_(True)
+        out = Em(X, A, graph_mode=True)
+        (out * torch.from_numpy(R)).sum().backward()
+        arrays.update({"out_" + tag: out.detach().numpy(), "gW_" + tag: vals.grad.numpy(), "gX_" + tag: X.grad.numpy(),
+                       "gV_" + tag: Em.projVecs.grad.numpy(), "gfreqs_" + tag: Em.freqs.grad.numpy()})
+    # dense weights, two point clouds of 40 points (non-graph mode), masses 0.6 and 1.7
+    B, npts = 2, 40
+    Xc = synth.normal(95, 1, (B, npts, d), dtype=np.float64)
+    Wc = synth.uniform01(96, 1, 0, B * npts).reshape(B, npts)
+    Wc = Wc / Wc.sum(axis=1, keepdims=True) * np.array([[0.6], [1.7]])
+    Rc = synth.normal(97, 1, (B, S), dtype=np.float64)
+    Em = emb.FSW_embedding(d_in=d, d_out=S, device="cpu", dtype=dt, load_custom_cuda_lib=False, enable_bias=False)
+    set_params(Em, V, fr)
+    Wt = torch.from_numpy(Wc).requires_grad_(True)
+    out = Em(torch.from_numpy(Xc), Wt)
+    (out * torch.from_numpy(Rc)).sum().backward()
+    arrays.update({"cloud_X": Xc, "cloud_W": Wc, "cloud_R": Rc, "cloud_out": out.detach().numpy(), "cloud_gW": Wt.grad.numpy()})
+    save("grads_w", **arrays)
+
+
+def case_testconv64(emb, conv):
+    """The configuration of the reference's own test_conv.py (:9-57) on deterministic inputs: float64, 100 vertices, 50 vertex /
+    11 edge features, 35 outputs, three MLP layers, homogeneous degree encoding with the 'log' function and a learnable scale,
+    self_loop_weight 0.2, final BatchNorm, eval mode; out, out(16 x) and the gradients of out.norm()."""
+    dt = torch.float64
+    n, dv, de, dout = 100, 50, 11, 35
+    ei = synth.er_multigraph(n, 1000, seed=101)
+    ei = ei[:, ei[0] < ei[1]]                                            # networkx G.edges: every undirected edge once
+    X0 = synth.normal(102, 1, (n, dv), dtype=np.float64)
+    E0 = synth.normal(103, 1, (ei.shape[1], de), dtype=np.float64)
+    torch.manual_seed(104)
+    C = conv.FSW_conv(dv, dout, edgefeat_dim=de, mlp_layers=3, bias=False, vertex_degree_encoding_function='log',
+                      vertex_degree_encoding_scale=1, learnable_vertex_degree_encoding_scale=True, homog_degree_encoding=True,
+                      learnable_embedding=True, concat_self=True, batchNorm_final=True, device="cpu", dtype=dt, self_loop_weight=0.2)
+    C.eval()
+    X = torch.from_numpy(X0).requires_grad_(True)
+    Ef = torch.from_numpy(E0).requires_grad_(True)
+    eit = torch.from_numpy(ei)
+    out = C(X, edge_index=eit, edge_features=Ef)
+    with torch.no_grad():
+        out2 = C(16 * X, edge_index=eit, edge_features=16 * Ef)
+    out.norm().backward()
+    arrays = {"edge_index": ei, "X": X0, "Ef": E0, "out": out.detach().numpy(), "out16": out2.numpy(),
+              "gX": X.grad.numpy(), "gEf": Ef.grad.numpy()}
+    for k, v in C.state_dict().items():
+        arrays["param." + k] = v.detach().numpy()
+    for k, p in C.named_parameters():
+        if p.grad is not None:
+            arrays["grad." + k] = p.grad.numpy()
+    save("testconv64", **arrays)
+
+
 def case_edgefeat(emb, conv):
     """Edge features (reference fsw_embedding.py:934-968, fsw_conv.py:419-439): FSW_conv with edgefeat_dim = 3 on
     the tiny multigraph (duplicate edges: the reference sums their features and weights in coalesce()), forward and
@@ -358,10 +428,14 @@ def main():
         case_coherence(emb)
     elif what == "edgefeat":
         case_edgefeat(emb, conv)
+    elif what == "grads_w":
+        case_grads_w(emb, conv)
+    elif what == "testconv64":
+        case_testconv64(emb, conv)
     elif what == "er1m":
         timings.update(case_er1m(emb, conv))
     else:
-        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|grads_homog|coherence|edgefeat|er1m]")
+        raise SystemExit("usage: python -m oracle.make_goldens [small|grads|grads_homog|coherence|edgefeat|grads_w|testconv64|er1m]")
     json.dump(timings, open(timings_path, "w"), indent=1, sort_keys=True)
 
 

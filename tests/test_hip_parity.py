@@ -767,9 +767,7 @@ def test_backward_tiny_graph_vs_reference_autograd(dev):
     assert relerr(E.projVecs.grad.cpu().numpy(), gg["gV_weighted"]) < 2e-5
     assert relerr(E.freqs.grad.cpu().numpy(), gg["gfreqs_weighted"]) < 2e-5
     assert abs(float(E.total_mass_encoding_scale.grad) - float(gg["gscale_weighted"])) < 1e-5 * abs(float(gg["gscale_weighted"]))
-    # gradients w.r.t. the weights are not provided: fail loudly
-    with pytest.raises(NotImplementedError):
-        E(X2, adj3.to_dense().requires_grad_(True), graph_mode=True)
+    # gradients w.r.t. the weights: tests/test_hip_float64.py::test_weight_gradients_vs_reference_autograd
 
 
 @pytest.mark.parametrize("method", ["homog", "homog_alt"])
