@@ -142,34 +142,38 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
   const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
   const int lane = lane_id();
   const int w = NW == 1 ? 0 : wave_id();
-  // block -> (row, slice): the blocks b, b + 8, b + 16, ... (one XCD under round-robin dispatch) take slices 0, 1, 2, ... of
-  // row xcd, then of row xcd + 8, ...
+  // virtual block -> (row, slice): the blocks b, b + 8, b + 16, ... (one XCD under round-robin dispatch) take slices 0, 1, 2,
+  // ... of row xcd, then of row xcd + 8, ...  The grid is capped (a dispatch holds < 2^32 work-items) and strides over the
+  // virtual blocks; gridDim.x is a multiple of 8, so a workgroup stays on its residue and leaves at its first row past the bin.
   const int xcd = blockIdx.x & 7;
-  const int64_t i = (int64_t)(blockIdx.x >> 3) * LPB + (NW == 1 ? wave_id() : 0);
-  const int64_t rl = i / S;
-  const int k = (int)(i - rl * S);
-  const int64_t r = rl * 8 + xcd;
-  if (r >= nrows) return;          // NW > 1: the whole workgroup leaves; NW == 1: no barrier below
-  const int node = perm[pbeg + r];
-  const int start = rowptr[node];
-  const int D = rowptr[node + 1] - start;
+  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
+    const int64_t i = (vb >> 3) * LPB + (NW == 1 ? wave_id() : 0);
+    const int64_t rl = i / S;
+    const int k = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;          // NW > 1: the whole workgroup leaves; NW == 1: no barrier below
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
 
-  WaveLine<M, false> ln;
-  gather_chunk<M>(ln, col + start, w * CAP, D, Xp, ldp, k, lane);
-  if (!(FSW_HUB_ABL & 2)) ln.sort();
-  if constexpr (NW > 1) workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
-  float tot = wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, freqs[k]));
-  if constexpr (NW > 1) {
-    if (lane == 0) red[w] = tot;
-    __syncthreads();
-    tot = 0.f;
+    WaveLine<M, false> ln;
+    gather_chunk<M>(ln, col + start, w * CAP, D, Xp, ldp, k, lane);
+    if (!(FSW_HUB_ABL & 2)) ln.sort();
+    if constexpr (NW > 1) workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
+    float tot = wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, freqs[k]));
+    if constexpr (NW > 1) {
+      if (lane == 0) red[w] = tot;
+      __syncthreads();
+      tot = 0.f;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) tot += red[q];
-  }
-  if (lane == 0 && w == 0) {
-    float* orow = out + (int64_t)node * ldo;
-    orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
-    if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+      for (int q = 0; q < NW; ++q) tot += red[q];
+      __syncthreads();               // red is rewritten by the next virtual block
+    }
+    if (lane == 0 && w == 0) {
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
   }
 }
 
@@ -319,8 +323,10 @@ int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t 
 template <int NW, int M>
 static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
   constexpr int LPB = NW == 1 ? 4 : 1;
-  const int64_t nblocks = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
-  FSW_REQUIRE(nblocks < (1ll << 31), "fsw_embed_f32: too many long rows x slices for one launch");
+  // virtual blocks = (rows rounded up to 8) x slices / lines per block; the launched grid is capped at 2^20 workgroups
+  // (a dispatch holds < 2^32 work-items: 17.7M x 256 threads were silently truncated on a 64M-edge graph) and strides
+  const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
+  const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
   k_embed_hub<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, 0, stream>>>(
       a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
       a.mass_scale);

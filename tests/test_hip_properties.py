@@ -100,3 +100,68 @@ def test_embedding_distance_approximates_sliced_wasserstein(dev):
     sw2 = np.sqrt(np.mean((np.sort(P.astype(np.float64) @ V.T, axis=0) - np.sort(Q.astype(np.float64) @ V.T, axis=0)) ** 2))
     dist = np.linalg.norm(eP - eQ) / np.sqrt(S)
     assert abs(dist - sw2) < 0.05 * sw2, (dist, sw2)
+
+
+def _rmat_on_device(scale, num_edges, seed, dev, a=0.57, b=0.19, c=0.19):
+    """Graph500-style RMAT edge list drawn on the GPU (the same quadrant rule as synth.rmat_graph; full-size graphs take
+    minutes with the counter-based numpy generator and no golden depends on this one)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    src = torch.zeros(num_edges, dtype=torch.int64, device=dev)
+    dst = torch.zeros(num_edges, dtype=torch.int64, device=dev)
+    for bit in range(scale):
+        u = torch.rand(num_edges, device=dev, generator=g)
+        src |= (u >= a + b).to(torch.int64) << bit
+        dst |= (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64) << bit
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize("config", ["config4_1024_slices", "config5_rmat22"])
+def test_baseline_configs_4_and_5_at_full_size(dev, config):
+    """BASELINE configs[3] (1M nodes / 10M edges, 1024 slices: one GPU computes all of them here) and configs[4] (RMAT scale 22,
+    4M nodes / 64M edges, 256 features, 256 slices: hubs of > 100 000 neighbours, every degree class) at FULL size through
+    FSW_conv.forward: finite; degree column exact; rows without in-edges exactly zero; positive homogeneity bit-exact for a
+    power of two; the edge list in another order gives the same bits; sampled rows of every degree class against the C oracle."""
+    from fsw_gnn_amd import FSW_conv
+    from oracle import c_oracle as C
+    if config == "config4_1024_slices":
+        n, E_, d, S = 1_000_000, 10_000_000, 128, 1024
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        ei = torch.randint(0, n, (2, E_), generator=g, dtype=torch.int64).to(dev)
+    else:
+        n, E_, d, S = 1 << 22, 64_000_000, 256, 256
+        ei = _rmat_on_device(22, E_, 22, dev)
+    X = torch.randn((n, d), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    torch.manual_seed(1)
+    conv = FSW_conv(d, S + 1, mlp_layers=0, concat_self=False, bias=False, device=dev)   # embed_dim = out_channels: the output IS the embedding
+    conv.fsw_embed.projVecs.requires_grad_(False)
+    conv.fsw_embed.freqs.requires_grad_(False)
+    with torch.no_grad():
+        base = conv(X, ei)
+        deg = torch.bincount(ei[1], minlength=n)
+        assert tuple(base.shape) == (n, S + 1) and bool(torch.isfinite(base).all())
+        assert torch.equal(base[:, 0], deg.to(torch.float32))
+        assert int((deg == 0).sum()) > 0 and float(base[deg == 0].abs().max()) == 0.0
+        if config == "config5_rmat22":
+            assert int(deg.max()) > 32768 and int(((deg > 2048) & (deg <= 32768)).sum()) > 0 and int(((deg > 256) & (deg <= 2048)).sum()) > 0
+        two = conv(2.0 * X, ei)
+        assert torch.equal(two[:, 1:], 2.0 * base[:, 1:])
+        del two
+        perm = torch.randperm(E_, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        assert torch.equal(conv(X, ei[:, perm].contiguous()), base)
+        del perm
+        # sampled rows against the C oracle (float64 arithmetic on the same float32 inputs): the largest row, and rows of every class
+        order = torch.argsort(ei[1], stable=True)
+        col = ei[0][order].cpu().numpy()
+        rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(deg, 0)]).cpu().numpy()
+        rows = [int(torch.argmax(deg))]
+        for lo, hi in ((0, 32), (32, 256), (256, 512), (512, 2048), (2048, 8192), (8192, 32768)):
+            cand = torch.nonzero((deg > lo) & (deg <= hi)).flatten()
+            if cand.numel():
+                rows += [int(cand[0]), int(cand[-1])]
+        rows = np.array(sorted(set(rows)), dtype=np.int64)
+        ref = C.embed(X.cpu().numpy(), rowptr, col, None, conv.fsw_embed.projVecs.detach().cpu().numpy(),
+                      conv.fsw_embed.freqs.detach().cpu().numpy(), rows=rows)
+        got = base[torch.from_numpy(rows).to(dev), 1:].cpu().numpy()
+        assert relerr(got, ref) < 1e-5
+        for i in range(rows.size):
+            assert relerr(got[i], ref[i]) < 2e-5, (int(rows[i]), int(deg[rows[i]]))
