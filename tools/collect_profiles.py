@@ -1,8 +1,13 @@
 """Copies the summaries of gpurun_out/refresh_TAG/ (tools/refresh_profiles.sh) into profiles/ as rNN_TAG_*:
 
-    python tools/collect_profiles.py TAG [prefix]     e.g.  python tools/collect_profiles.py v5 r01
+    python tools/collect_profiles.py TAG [prefix]     e.g.  python tools/collect_profiles.py v1 r02
+
+The PMC traffic file records where it came from (git HEAD and date of the capture) so that bench.py can say so
+("traffic_source") when it quotes the number.
 """
+import datetime
 import glob
+import json
 import os
 import shutil
 import subprocess
@@ -10,16 +15,34 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "r01"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(root, "gpurun_out", "refresh_" + tag)
 dst = os.path.join(root, "profiles")
 name = "%s_%s" % (prefix, tag)
+
+
+def stats_of(sub):
+    return glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)[0]
+
+
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, name + "_bench.json"))
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
-shutil.copy(stats[0], os.path.join(dst, name + "_bench_kernel_stats.csv"))
+shutil.copy(stats_of("stats"), os.path.join(dst, name + "_bench_kernel_stats.csv"))
 fetch = glob.glob(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)[0]
 write = glob.glob(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"), recursive=True)[0]
-subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), fetch, write,
-                       os.path.join(dst, "pmc_traffic_latest.json")])
-shutil.copy(os.path.join(dst, "pmc_traffic_latest.json"), os.path.join(dst, name + "_pmc_traffic.json"))
+latest = os.path.join(dst, "pmc_traffic_latest.json")
+subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), fetch, write, latest])
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+t = json.load(open(latest))
+t["source"] = {"git_head": head, "captured": datetime.datetime.now().isoformat(timespec="seconds"),
+               "how": "tools/refresh_profiles.sh %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py" % tag}
+json.dump(t, open(latest, "w"), indent=1)
+shutil.copy(latest, os.path.join(dst, name + "_pmc_traffic.json"))
+for sub, out in (("rmat22", "_rmat22_forward_kernel_stats.csv"), ("segcumsum", "_segcumsum_kernel_stats.csv")):
+    try:
+        shutil.copy(stats_of(sub), os.path.join(dst, name + out))
+    except IndexError:
+        print("no", sub, "profile in", src)
+for f in ("segcumsum.json",):
+    if os.path.isfile(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, name + "_" + f))
 print("profiles/%s_* written" % name)

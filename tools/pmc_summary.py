@@ -28,7 +28,7 @@ def main():
     for k in sorted(fetch, key=lambda k: -fetch[k])[:12]:
         f, w = fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
         rows.append({"kernel": k[:80], "fetch_raw_bytes": f, "write_bytes": w, "hbm_bytes_corrected": 2 * f + w})
-        for name in ("k_embed_reg_unit", "k_conv_fused_unit", "k_project", "k_rs_downsweep"):
+        for name in ("k_embed_reg_unit", "k_conv_fused_unit", "k_project", "k_rs_downsweep", "k_rs_upsweep", "k_segscan_chained"):
             if name in k:
                 out.setdefault(name + "_hbm_bytes_per_launch", 2 * f + w)
     out["kernels"] = rows
