@@ -75,7 +75,9 @@ _SIGNATURES = {
                                           ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     "fsw_unit_dcoeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_backward_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
-    "fsw_embed_backward_keys_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_embed_backward_keys_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_graph_transpose": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "fsw_segment_sum_rows_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_generic_scratch_bytes": (c_sz, [c_i64, c_i64]),
     "fsw_embed_generic": (ctypes.c_int, [ctypes.POINTER(GenericArgs), c_vp]),
     "fsw_project_f64": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),

@@ -47,7 +47,8 @@ __device__ __forceinline__ void unit_bwd_rows(int p, int pe, const int32_t* __re
                                               const float* __restrict__ table, const float* __restrict__ dtable, int64_t ldt,
                                               const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
                                               float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
-                                              float* __restrict__ cS /* [2][D][64] wave-private LDS */, int k, int kc, bool kvalid) {
+                                              float* __restrict__ cS /* [2][D][64] wave-private LDS */, int k, int kc, bool kvalid,
+                                              float* __restrict__ gkey, int64_t ldk) {
   const int lane = lane_id();
   const int64_t trow = (int64_t)(D * (D - 1) / 2);
 #pragma unroll
@@ -84,7 +85,10 @@ __device__ __forceinline__ void unit_bwd_rows(int p, int pe, const int32_t* __re
       const float c = cS[rank[t] * kWave + lane];
       const float dc = cS[(D + rank[t]) * kWave + lane];
       gf = fmaf(gi * dc, key[t], gf);
-      if (kvalid) atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * c);
+      if (kvalid) {
+        if (gkey) gkey[(int64_t)(start + t) * ldk + k] = gi * c;   // store-and-sum form: one plain 256-byte store per neighbour
+        else atomicAdd(gXp + (int64_t)cidx[t] * ldgp + k, gi * c);
+      }
     }
   }
   if (kvalid && gfreq) atomicAdd(gfreq + k, gf);
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit_bwd(const int32_t* __res
                                                             const float* __restrict__ table, const float* __restrict__ dtable,
                                                             int64_t ldt, const float* __restrict__ g, int64_t ldg, int gcol0,
                                                             float out_scale, float* __restrict__ gXp, int64_t ldgp,
-                                                            float* __restrict__ gfreq) {
+                                                            float* __restrict__ gfreq, float* __restrict__ gkey, int64_t ldk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wv = wave_id();
   const int chunk = blockIdx.y * 4 + wv;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit_bwd(const int32_t* __res
   case d:                                                                                                             \
     if constexpr (d >= DLO && d <= DHI)                                                                               \
       unit_bwd_rows<d>(p, pe, rowptr, col, perm, Xp, ldp, table, dtable, ldt, g, ldg, gcol0, out_scale, gXp, ldgp,    \
-                       gfreq, cS, k, kc, kvalid);                                                                     \
+                       gfreq, cS, k, kc, kvalid, gkey, ldk);                                                          \
     break;
     FSW_BWD_CASES(X)
 #undef X
@@ -285,7 +289,9 @@ static int embed_backward_impl(const fsw_embed_args* args, const float* dtable, 
   FSW_REQUIRE(gkey ? ldk >= a.S : ldgp >= a.S, "fsw_embed_backward: bad gradient stride");
   FSW_REQUIRE(!a.efeat || (a.w && a.Ve && a.d_edge >= 1 && a.ldve >= a.d_edge && gkey),
               "fsw_embed_backward: edge features need a coalesced weighted graph, Ve and the key-gradient form");
-  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f) && !gkey;
+  // unit-weight register rows use the coefficient tables; the key-gradient form may come without them (edge-feature
+  // graphs are weighted anyway) and then takes the general kernels with w = 1
+  const bool unit_fast = (a.w == nullptr) && (a.tau <= 1.f) && (!gkey || (a.unit_table && dtable));
   FSW_REQUIRE(!unit_fast || (a.unit_table && dtable && a.ldt >= a.S),
               "fsw_embed_backward: unit weights with tau <= 1 need unit_table and dtable");
   const int64_t nreg = a.num_reg_rows < 0 ? a.num_rows : a.num_reg_rows;
@@ -297,11 +303,11 @@ static int embed_backward_impl(const fsw_embed_args* args, const float* dtable, 
       // long rows first; the two launches differ in the LDS they need for the wave-private coefficient rows
       k_embed_reg_unit_bwd<17, 32><<<grid, 256, 4 * 2 * 32 * kWave * sizeof(float), stream>>>(
           a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale,
-          gXp, ldgp, gfreq);
+          gXp, ldgp, gfreq, gkey, ldk);
       FSW_LAUNCH_CHECK();
       k_embed_reg_unit_bwd<1, 16><<<grid, 256, 4 * 2 * 16 * kWave * sizeof(float), stream>>>(
           a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, dtable, a.ldt, g, ldg, a.has_mass, a.out_scale,
-          gXp, ldgp, gfreq);
+          gXp, ldgp, gfreq, gkey, ldk);
       FSW_LAUNCH_CHECK();
     } else {
       k_embed_reg_weighted_bwd<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs,
@@ -322,8 +328,84 @@ extern "C" int fsw_embed_backward_f32(const fsw_embed_args* args, const float* d
   return embed_backward_impl(args, dtable, g, ldg, gXp, ldgp, gfreq, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int64_t ldg, float* gkey, int64_t ldk,
-                                           float* gfreq, fsw_stream_t stream) {
+extern "C" int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gkey,
+                                           int64_t ldk, float* gfreq, fsw_stream_t stream) {
   FSW_REQUIRE(gkey, "fsw_embed_backward_keys_f32: null gkey");
-  return embed_backward_impl(args, nullptr, g, ldg, nullptr, 0, gfreq, gkey, ldk, reinterpret_cast<hipStream_t>(stream));
+  return embed_backward_impl(args, dtable, g, ldg, nullptr, 0, gfreq, gkey, ldk, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- store-and-sum: gXp[j, :] = sum of the key-gradient rows of j's out-edges -------------------------------------------------
+// Second half of the atomic-free backward: the kernels above stored one contribution row per CSR entry (gkey); here every
+// workgroup takes kSegLen CONSECUTIVE entries of the sender-major order (fsw_graph_transpose) -- perfectly balanced whatever the
+// out-degrees -- walks the senders covering them (wave = 64-slice chunk, lane = slice: one coalesced 256-byte row gather per
+// entry, 8 in flight) and writes a sender's sum with a plain store when its whole list lies inside the segment, with one
+// wave-wide float atomic otherwise (out is zeroed by the caller; two partial sums commute, so results stay bitwise reproducible
+// for senders of up to 2 segments; longer lists -- hubs -- add in arrival order).
+constexpr int kSegLen = 256;
+
+__global__ void __launch_bounds__(256) k_segment_sum_rows(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ ptr,
+                                                          const int32_t* __restrict__ order, int64_t num_out, int64_t nnz, int S,
+                                                          float* __restrict__ out, int64_t ldo) {
+  const int chunk = blockIdx.y * 4 + wave_id();
+  if (chunk * kWave >= S) return;
+  const int k = chunk * kWave + lane_id();
+  const bool kvalid = k < S;
+  const int kc = kvalid ? k : S - 1;
+  const int64_t q0 = (int64_t)blockIdx.x * kSegLen, q1 = min(q0 + kSegLen, nnz);
+  // sender of entry q0: the largest j with ptr[j] <= q0 (wave-uniform binary search)
+  int64_t lo = 0, hi = num_out;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)ptr[mid] <= q0) lo = mid; else hi = mid;
+  }
+  int64_t j = lo;
+  int64_t nextb = ptr[j + 1];
+  while (nextb <= q0) {          // ptr[j] == ptr[j + 1] == q0 runs of empty senders: take the last j with ptr[j] <= q0 < ptr[j + 1]
+    ++j;
+    nextb = ptr[j + 1];
+  }
+  float acc = 0.f;
+  auto flush = [&](int64_t jj) {
+    const bool complete = (int64_t)ptr[jj] >= q0 && (int64_t)ptr[jj + 1] <= q1;
+    if (kvalid) {
+      if (complete) out[jj * ldo + k] = acc;
+      else atomicAdd(out + jj * ldo + k, acc);
+    }
+    acc = 0.f;
+  };
+  constexpr int kDepth = 8;
+  for (int64_t qb = q0; qb < q1; qb += kDepth) {
+    float v[kDepth];
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) {
+      const int64_t q = min(qb + u, q1 - 1);
+      v[u] = src[(int64_t)order[q] * lds + kc];
+    }
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) {
+      const int64_t q = qb + u;
+      if (q < q1) {
+        while (q == nextb) {
+          flush(j);
+          ++j;
+          nextb = ptr[j + 1];
+        }
+        acc += v[u];
+      }
+    }
+  }
+  flush(j);
+}
+
+extern "C" int fsw_segment_sum_rows_f32(const float* src, int64_t lds, const int32_t* ptr, const int32_t* order, int64_t num_out,
+                                        int64_t nnz, int S, float* out, int64_t ldo, fsw_stream_t stream) {
+  FSW_REQUIRE(src && ptr && order && out, "fsw_segment_sum_rows_f32: null pointer");
+  FSW_REQUIRE(S >= 1 && lds >= S && ldo >= S && num_out >= 1 && nnz >= 0,
+              "fsw_segment_sum_rows_f32: need S >= 1, lds >= S, ldo >= S, num_out >= 1, nnz >= 0 (got S %d, lds %lld, ldo %lld, num_out %lld, nnz %lld)", S,
+              (long long)lds, (long long)ldo, (long long)num_out, (long long)nnz);
+  if (nnz == 0) return 0;
+  dim3 grid((unsigned)ceil_div(nnz, kSegLen), (unsigned)ceil_div(S, 4 * kWave));
+  k_segment_sum_rows<<<grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(src, lds, ptr, order, num_out, nnz, S, out, ldo);
+  FSW_LAUNCH_CHECK();
+  return 0;
 }

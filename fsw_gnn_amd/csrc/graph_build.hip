@@ -363,9 +363,10 @@ __global__ void __launch_bounds__(256) k_bin_count(const int32_t* __restrict__ r
 
 __global__ void __launch_bounds__(kMaxRowChunks) k_bin_offsets(const int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_start,
                                                                int32_t* __restrict__ bin_cursor, int32_t* __restrict__ stats,
-                                                               int num_chunks) {
+                                                               int num_chunks, const int32_t* __restrict__ rowptr, int64_t num_rows) {
   __shared__ int ctot[kMaxRowChunks];
   const int c = threadIdx.x;
+  if (c == 0) stats[FSW_STAT_NNZ] = rowptr[num_rows];   // CSR entries in use (invalid edges dropped, parallel edges merged or not)
   int tot = 0;
   if (c < num_chunks)
     for (int b = 0; b < FSW_NUM_BINS; ++b) tot += bin_count[c * FSW_NUM_BINS + b];
@@ -600,11 +601,21 @@ static int finish_bins(int32_t* rowptr, int64_t num_rows, int64_t chunk_rows, in
   const int row_blocks = (int)ceil_div(num_rows, kBinRowsPerBlock);
   k_bin_count<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, chunk_rows, g.bin_count, stats);
   FSW_LAUNCH_CHECK();
-  k_bin_offsets<<<1, kMaxRowChunks, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats, num_chunks);
+  k_bin_offsets<<<1, kMaxRowChunks, 0, stream>>>(g.bin_count, bin_start, g.bin_cursor, stats, num_chunks, rowptr, num_rows);
   FSW_LAUNCH_CHECK();
   k_bin_rows<<<row_blocks, 256, 0, stream>>>(rowptr, num_rows, chunk_rows, g.bin_cursor, perm, invperm);
   FSW_LAUNCH_CHECK();
   return 0;
+}
+
+// keys = the sender of every CSR entry, values = the entry's position: the input of the sender-major sort (fsw_graph_transpose)
+__global__ void __launch_bounds__(256) k_entry_keys(const int32_t* __restrict__ col, int64_t nnz, int64_t num_cols,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t c = col[i];
+    keys[i] = (c < 0 || c >= num_cols) ? (uint32_t)num_cols : (uint32_t)c;
+    vals[i] = (uint32_t)i;
+  }
 }
 
 static int check_chunks(int64_t num_rows, int64_t chunk_rows) {
@@ -707,4 +718,30 @@ extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_
   k_rowptr_from_keys<<<edge_blocks, 256, 0, stream>>>(keyc, nnz_dev, num_rows, rowptr);
   FSW_LAUNCH_CHECK();
   return finish_bins(rowptr, num_rows, 0, perm, invperm, bin_start, stats, g, stream);
+}
+
+// Sender-major view of a built graph: cptr[j] .. cptr[j + 1] index the entries of `order` that list, in CSR order, the CSR
+// positions e with col[e] == j.  The backward pass sums the stored key gradients over it (fsw_segment_sum_rows_f32) instead of
+// scattering them with float atomics.  A stable LSD sort of (col[e], e): the CSR build's own passes.
+extern "C" int fsw_graph_transpose(const int32_t* col, int64_t nnz, int64_t num_cols, int32_t* cptr, int32_t* order, void* workspace,
+                                   size_t workspace_bytes, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  FSW_REQUIRE(num_cols >= 1 && num_cols < (1ll << 31) - 1 && nnz >= 0 && nnz < (1ll << 31) - kRsTile,
+              "fsw_graph_transpose: sizes must satisfy 1 <= cols < 2^31 and 0 <= nnz < 2^31");
+  FSW_REQUIRE(cptr && workspace && workspace_bytes >= fsw_graph_workspace_bytes(num_cols, nnz) && (nnz == 0 || (col && order)),
+              "fsw_graph_transpose: null pointer or workspace too small");
+  if (nnz == 0) {
+    FSW_CHECK_HIP(hipMemsetAsync(cptr, 0, sizeof(int32_t) * (size_t)(num_cols + 1), stream));
+    return 0;
+  }
+  GraphWs g = carve(workspace, nnz);
+  const int blocks = (int)std::min<int64_t>(ceil_div(nnz + 1, 256), 256 * 32);
+  k_entry_keys<<<blocks, 256, 0, stream>>>(col, nnz, num_cols, g.keys[0], reinterpret_cast<uint32_t*>(g.vals[0]));
+  FSW_LAUNCH_CHECK();
+  int cur = 0;
+  if (int rc = radix_sort_pairs<uint32_t, true>(nullptr, nullptr, nullptr, true, nnz, num_cols, num_cols, nullptr, g, &cur, stream)) return rc;
+  k_finish_csr<uint32_t><<<blocks, 256, 0, stream>>>(g.keys[cur], reinterpret_cast<const uint32_t*>(g.vals[cur]), nnz, num_cols, cptr, order,
+                                                     nullptr);
+  FSW_LAUNCH_CHECK();
+  return 0;
 }

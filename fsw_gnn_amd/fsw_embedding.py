@@ -106,7 +106,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             gkey = torch.zeros((max(nnz, 1), S), dtype=torch.float32, device=X.device)
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
             a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch, slice_offset=ka)
-            _lib.check(L.fsw_embed_backward_keys_f32(ctypes.byref(a), _lib.ptr(g), g.stride(0), _lib.ptr(gkey), S, _lib.ptr(gf), stream),
+            _lib.check(L.fsw_embed_backward_keys_f32(ctypes.byref(a), None, _lib.ptr(g), g.stride(0), _lib.ptr(gkey), S, _lib.ptr(gf), stream),
                        "fsw_embed_backward_keys_f32")
             gkey, ef = gkey[:nnz], graph.ef[:nnz]
             if need_xp:
@@ -132,8 +132,20 @@ class _EmbedGraphFn(torch.autograd.Function):
                 scratch = torch.empty(int(L.fsw_embed_scratch_bytes(st[_lib.STAT_MAX_DEGREE])), dtype=torch.uint8, device=X.device)
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
             a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch, slice_offset=ka)
-            _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
-                                                _lib.ptr(gf), stream), "fsw_embed_backward_f32")
+            nnz = st[_lib.STAT_NNZ]
+            if prepared["unit_fast"] and need_xp and 0 < nnz * S * 4 <= module.store_sum_backward_max_bytes:
+                # store-and-sum: every neighbour's key gradient is stored once (plain stores), then summed sender by sender over
+                # the sender-major entry list -- no float atomics, reproducible gradients
+                gkey = torch.empty((nnz, S), dtype=torch.float32, device=X.device)
+                cptr, order = graph.sender_major()
+                _lib.check(L.fsw_embed_backward_keys_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gkey), S,
+                                                         _lib.ptr(gf), stream), "fsw_embed_backward_keys_f32")
+                _lib.check(L.fsw_segment_sum_rows_f32(_lib.ptr(gkey), S, _lib.ptr(cptr), _lib.ptr(order), graph.num_cols, nnz, S,
+                                                      _lib.ptr(gXp), ldp, stream), "fsw_segment_sum_rows_f32")
+                del gkey
+            else:
+                _lib.check(L.fsw_embed_backward_f32(ctypes.byref(a), _lib.ptr(dtable), _lib.ptr(g), g.stride(0), _lib.ptr(gXp), ldp,
+                                                    _lib.ptr(gf), stream), "fsw_embed_backward_f32")
             if ctx.needs_input_grad[0]:
                 gX = gXp[:, :S] @ V[:, :module.d_in]
             if ctx.needs_input_grad[1]:
@@ -681,6 +693,9 @@ class FSW_embedding(nn.Module):
         return self._homog_epilogue(P, out_scale, bias)
 
     # ------------------------------------------------------------------------------------------------
+    # backward of unit-weight graphs: store the key gradients ([nnz, nSlices] float32) and sum them sender by sender instead of
+    # float atomics, as long as that buffer stays below this size (10.2 GB at 10M edges x 256 slices); 0 = always atomics
+    store_sum_backward_max_bytes = 32 << 30
     _force_plain = False   # embed_autograd: 'plain' mass column and no bias from the kernels, epilogue in torch
 
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None, slice_range=None):

@@ -29,6 +29,24 @@ class CSRGraph:
         self.ef = ef                        # [num_edges, d_edge] summed edge features of the coalesced entries, or None
         self.slot_of_edge = slot_of_edge    # int32[num_input_edges]: CSR entry of every input edge (coalesced build)
         self._stats = None
+        self._sender_major = None
+
+    def sender_major(self):
+        """(cptr int32[num_cols + 1], order int32[nnz]): the CSR entries listed sender by sender (fsw_graph_transpose), built on
+        first use and kept with the graph; the store-and-sum backward sums the stored key gradients over it."""
+        if self._sender_major is None:
+            L = _lib.lib()
+            nnz = self.stats()[_lib.STAT_NNZ]
+            dev = self.rowptr.device
+            cptr = torch.empty(self.num_cols + 1, dtype=torch.int32, device=dev)
+            order = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+            ws_bytes = int(L.fsw_graph_workspace_bytes(self.num_cols, nnz))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(L.fsw_graph_transpose(_lib.ptr(self.col), nnz, self.num_cols, _lib.ptr(cptr), _lib.ptr(order), _lib.ptr(ws), ws_bytes,
+                                             stream), "fsw_graph_transpose")
+            self._sender_major = (cptr, order)
+        return self._sender_major
 
     def read_stats(self):
         """Fresh host copy of the stats words (one small device->host copy; synchronises the stream)."""

@@ -72,7 +72,7 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
 #define FSW_STAT_NUM_REG 3      /* rows with 1 <= degree <= FSW_REG_MAX_DEG */
 #define FSW_STAT_NUM_LDS 4      /* rows with FSW_REG_MAX_DEG < degree <= FSW_LDS_MAX_DEG (mid bins + LDS bin) */
 #define FSW_STAT_NUM_GLOBAL 5   /* rows with degree > FSW_LDS_MAX_DEG (hub bins + global bin) */
-#define FSW_STAT_NNZ 6          /* fsw_graph_build_coalesced: number of CSR entries after coalescing */
+#define FSW_STAT_NNZ 6          /* number of CSR entries in use = rowptr[num_rows] (after coalescing, without invalid edges) */
 #define FSW_STAT_USER 7         /* never written by the library after the build zeroes it: the Python side parks the bits of
                                    the total-mass scale here so that ONE device->host copy per forward fetches everything */
 #define FSW_NUM_STATS 8
@@ -242,8 +242,19 @@ int fsw_embed_backward_f32(const fsw_embed_args* args, const float* dtable, cons
 /* Edge-feature graphs: the same backward, but the gradient of every KEY is stored instead of being accumulated:
  * gkey[e*ldk + k] = out_scale * g[i,k] * C(entry e, slice k) for CSR entry e of row i (gkey zeroed by the caller).
  * From it: gXp = scatter-add of gkey rows by col, g_efeat = gkey . Ve, gVe = gkey^T . efeat.               */
-int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* g, int64_t ldg, float* gkey, int64_t ldk,
-                                float* gfreq, fsw_stream_t stream);
+int fsw_embed_backward_keys_f32(const fsw_embed_args* args, const float* dtable, const float* g, int64_t ldg, float* gkey,
+                                int64_t ldk, float* gfreq, fsw_stream_t stream);
+/* Store-and-sum backward (no float atomics on the register rows; the reference's own backward is an index_add of the same
+ * terms, ag.permute_sparse.backward fsw_embedding.py:1286): fsw_embed_backward_keys_f32 with dtable != NULL stores the key
+ * gradients of a unit-weight graph, fsw_graph_transpose lists the CSR entries sender by sender (cptr [num_cols + 1], order [nnz];
+ * workspace of fsw_graph_workspace_bytes(num_cols, nnz) bytes; entries whose col is out of range sort last and belong to no
+ * sender), and fsw_segment_sum_rows_f32 forms out[j, 0:S] = sum over q in cptr[j] .. cptr[j+1]-1 of src[order[q], 0:S].
+ * `out` must be zeroed by the caller (senders without out-edges are not written; a sender whose list crosses a 256-entry
+ * segment boundary is accumulated).  Sums of up to two segments are bitwise reproducible.                    */
+int fsw_graph_transpose(const int32_t* col, int64_t nnz, int64_t num_cols, int32_t* cptr, int32_t* order, void* workspace,
+                        size_t workspace_bytes, fsw_stream_t stream);
+int fsw_segment_sum_rows_f32(const float* src, int64_t lds, const int32_t* ptr, const int32_t* order, int64_t num_out, int64_t nnz,
+                             int S, float* out, int64_t ldo, fsw_stream_t stream);
 
 /* ---- generic neighbourhood kernels: any in-degree, float32 or float64 storage, float64 arithmetic ------------------------
  * (csrc/embed_generic.hip)  Two uses:

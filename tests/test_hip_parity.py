@@ -864,6 +864,74 @@ def test_hub_row_with_100k_neighbours_forward_and_backward(dev):
         assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
 
 
+def test_store_and_sum_backward_matches_atomic_backward_and_is_reproducible(dev):
+    """Unit-weight graphs store every neighbour's key gradient and sum them over the sender-major entry list
+    (fsw_graph_transpose + fsw_segment_sum_rows_f32) instead of float atomics.  A graph with a sender of out-degree 6000 (its
+    list crosses 24 segments), senders without out-edges, every in-degree class up to the scratch rows: the C entry points
+    against torch's stable sort / index_add, the gradients against the atomic form (store_sum_backward_max_bytes = 0) and
+    the oracle, and two runs of an ER graph bitwise equal."""
+    import ctypes
+    from fsw_gnn_amd import build_csr, _lib
+    rng = np.random.default_rng(77)
+    n, d, S = 9000, 7, 70
+    deg = rng.choice([0, 1, 2, 3, 5, 9, 17, 33, 40, 70, 130, 300, 2100], size=n, p=[.1, .2, .2, .15, .1, .08, .06, .05, .03, .02, .006, .003, .001])
+    deg[:6000] = np.maximum(deg[:6000], 1)
+    rec = np.repeat(np.arange(n), deg).astype(np.int64)
+    snd = rng.integers(100, n, size=rec.size).astype(np.int64)      # senders 0..99 mostly without out-edges
+    first = np.concatenate([[0], np.cumsum(deg)[:-1]])[:6000]
+    snd[first] = 7                                                   # one sender of out-degree 6000, no duplicates inside a row
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=5)
+    fr = cases.random_freqs(S, seed=6)
+    R = rng.standard_normal((n, S))
+    graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None, n, n)
+    nnz = graph.stats()[_lib.STAT_NNZ]
+    # the two C entry points on their own
+    cptr, order = graph.sender_major()
+    col = graph.col[:nnz].long()
+    ref_order = torch.sort(col, stable=True).indices
+    assert torch.equal(order[:nnz].long(), ref_order)
+    assert torch.equal(cptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(col, minlength=n).cumsum(0)]))
+    src = torch.randn(nnz, S, device=dev)
+    got = torch.zeros(n, 128, device=dev)
+    L = _lib.lib()
+    _lib.check(L.fsw_segment_sum_rows_f32(_lib.ptr(src), S, _lib.ptr(cptr), _lib.ptr(order), n, nnz, S, _lib.ptr(got), 128,
+                                          torch.cuda.current_stream().cuda_stream), "fsw_segment_sum_rows_f32")
+    torch.cuda.synchronize()
+    want = torch.zeros(n, S, device=dev, dtype=torch.float64).index_add_(0, col, src.double())
+    assert float((got[:, :S].double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    assert float(got[:, S:].abs().max()) == 0.0
+    # gradients: store-and-sum against atomics against the oracle
+    grads = {}
+    for mode, limit in (("store", 32 << 30), ("atomic", 0)):
+        E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+        E.store_sum_backward_max_bytes = limit
+        Xd = t(X, dev).requires_grad_(True)
+        out = E.embed_autograd(Xd, graph)
+        (out * t(R, dev)).sum().backward()
+        grads[mode] = (Xd.grad.cpu().numpy(), E.projVecs.grad.cpu().numpy(), E.freqs.grad.cpu().numpy())
+        xp = _hip_projection(E, Xd)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, graph.col[:nnz].cpu().numpy().astype(np.int64), np.ones(nnz), V, fr, R, Xp_override=xp)
+    for mode in grads:
+        assert relerr(grads[mode][0], gX) < 3e-5 and relerr(grads[mode][1], gV) < 3e-5 and relerr(grads[mode][2], gxi) < 3e-5, mode
+    assert relerr(grads["store"][0], grads["atomic"][0]) < 1e-5
+    # bitwise reproducible where no sender's list spans more than two segments
+    m = 20000
+    rec2 = rng.integers(0, m, size=200000).astype(np.int64)
+    snd2 = rng.integers(0, m, size=200000).astype(np.int64)
+    g2 = build_csr(t(rec2, dev, torch.int64), t(snd2, dev, torch.int64), None, m, m)
+    X2 = rng.standard_normal((m, d)).astype(np.float32)
+    R2 = t(rng.standard_normal((m, S)), dev)
+    runs = []
+    for _ in range(2):
+        E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+        Xd = t(X2, dev).requires_grad_(True)
+        (E.embed_autograd(Xd, g2) * R2).sum().backward()
+        runs.append(Xd.grad.clone())
+    assert torch.equal(runs[0], runs[1])
+
+
 def test_backward_conv10k_training_step(dev):
     gg = golden("grads_conv10k")
     c = cases.conv10k()
