@@ -27,7 +27,7 @@ constexpr int kRsThreads = 256;
 constexpr int kRsItems = 16;                      // rounds of 64 consecutive edges per wave
 constexpr int kRsTile = kRsThreads * kRsItems;    // 4096 edges per tile
 constexpr int kRsWaves = kRsThreads / kWave;
-constexpr int kRsMaxDigits = 256;
+constexpr int kRsMaxDigits = 512;                 // 9 bits: the bucket pass of the two-level build (below)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __re
     unsigned long long peers = __ballot(ok) ;
     if (!ok) peers = ~peers;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < 9; ++b) {
       if (b < nbits) {
         const unsigned long long bb = __ballot((d >> b) & 1u);
         peers &= ((d >> b) & 1u) ? bb : ~bb;
@@ -249,18 +249,19 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __re
     dstart[d] = acc;  // tile total for now
   }
   __syncthreads();
-  if (threadIdx.x < kWave) {  // exclusive scan of the tile totals over the digits (<= 256 = 4 per lane)
-    int v[4], s = 0;
+  if (threadIdx.x < kWave) {  // exclusive scan of the tile totals over the digits (<= kRsMaxDigits = 8 per lane)
+    constexpr int kPer = kRsMaxDigits / kWave;
+    int v[kPer], s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int d = lane * 4 + j;
+    for (int j = 0; j < kPer; ++j) {
+      const int d = lane * kPer + j;
       v[j] = d < ndigits ? dstart[d] : 0;
       s += v[j];
     }
     int ex = wave_inclusive_scan(s) - s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int d = lane * 4 + j;
+    for (int j = 0; j < kPer; ++j) {
+      const int d = lane * kPer + j;
       if (d < ndigits) dstart[d] = ex;
       ex += v[j];
     }
@@ -450,12 +451,13 @@ struct GraphWs {
   void* vals[2];
   int32_t* counts;      // [ndigits][ntiles]
   int32_t* block_sums;  // scan scratch
+  int32_t* block_sums_big;  // bucket starts of the two-level build (multi-pass case): rows / 2^11 + 2 entries
   int32_t* bin_count;
   int32_t* bin_cursor;
   size_t total;
 };
 
-static GraphWs carve(void* ws, int64_t num_edges) {
+static GraphWs carve(void* ws, int64_t num_edges, int64_t num_rows = 0) {
   const size_t E = (size_t)std::max<int64_t>(num_edges, 1);
   const size_t ntiles = (size_t)ceil_div((int64_t)E, kRsTile);
   char* p = reinterpret_cast<char*>(ws);
@@ -471,6 +473,7 @@ static GraphWs carve(void* ws, int64_t num_edges) {
   g.vals[1] = take(8 * E);
   g.counts = reinterpret_cast<int32_t*>(take(4 * (size_t)kRsMaxDigits * ntiles));
   g.block_sums = reinterpret_cast<int32_t*>(take(4 * (size_t)(ceil_div((int64_t)(kRsMaxDigits * ntiles), kScanTile) + 1)));
+  g.block_sums_big = reinterpret_cast<int32_t*>(take(4 * (size_t)((num_rows >> 10) + 3)));
   g.bin_count = reinterpret_cast<int32_t*>(take(kBinTableBytes));
   g.bin_cursor = reinterpret_cast<int32_t*>(take(kBinTableBytes));
   g.total = (size_t)(p - reinterpret_cast<char*>(ws));
@@ -481,18 +484,26 @@ static GraphWs carve(void* ws, int64_t num_edges) {
 // (key = first_a[e], valid when 0 <= first_a[e] < range_a and 0 <= first_b[e] < range_b; invalid edges get the
 // sentinel key range_a and sort last).  keys_in != NULL: pre-built uint32 keys instead (values from g.vals[*cur]).
 // On return *cur selects the ping-pong buffer that holds the result.
+static int key_bits(int64_t range_a) {
+  int keybits = 1;
+  while ((1ll << keybits) <= range_a) ++keybits;  // values 0 .. range_a (sentinel) must fit
+  return keybits;
+}
+
+// lo_bit > 0: only the key bits from lo_bit upwards are sorted (the two-level build finishes the low bits bucket by bucket),
+// in passes of up to max_bits bits.
 template <class VAL, bool EID>
 static int radix_sort_pairs(const int64_t* first_a, const int64_t* first_b, const float* edge_w, bool from_keys,
                             int64_t num_edges, int64_t range_a, int64_t range_b, int32_t* stats, GraphWs& g, int* cur_io,
-                            hipStream_t stream) {
-  int keybits = 1;
-  while ((1ll << keybits) <= range_a) ++keybits;  // values 0 .. range_a (sentinel) must fit
-  const int npass = (keybits + 7) / 8;
+                            hipStream_t stream, int lo_bit = 0, int max_bits = 8, int* last_bits = nullptr) {
+  const int keybits = key_bits(range_a) - lo_bit;
+  const int npass = (keybits + max_bits - 1) / max_bits;
   const int bits = (keybits + npass - 1) / npass;
+  if (last_bits) *last_bits = bits;
   const int64_t ntiles = ceil_div(num_edges, kRsTile);
   int cur = *cur_io;
   for (int pass = 0; pass < npass; ++pass) {
-    const int shift = pass * bits;
+    const int shift = lo_bit + pass * bits;
     const int ndigits = 1 << bits;
     const bool first = (pass == 0) && !from_keys;
     const uint32_t* kin = g.keys[cur];
@@ -608,6 +619,191 @@ static int finish_bins(int32_t* rowptr, int64_t num_rows, int64_t chunk_rows, in
   return 0;
 }
 
+// ---- two-level build: one partition pass over the high key bits, then every bucket of 2^rb rows finished by ONE workgroup ----
+// The LSD build above moves every edge three times at 1M rows (3 x 7 bits) and pays 3 x (upsweep, three scan launches,
+// downsweep).  Here one pass (same kernels, up to 9 bits) groups the edges by bucket = row >> rb, stably; a bucket then holds
+// ~E / buckets edges of 2^rb <= 2048 consecutive rows, and one workgroup finishes it without further global passes:
+//   1. every wave histograms ITS contiguous part of the bucket over the 2^rb rows (wave-private LDS table),
+//   2. exclusive scan over the waves per row (= where each wave's entries of a row start inside the row) and over the rows
+//      (= rowptr of the bucket's rows: the bucket's start is already the number of edges of all smaller rows),
+//   3. every wave walks its part again in order: wave64 match on the row bits gives the rank among the round's 64 edges, the
+//      wave-private cursor the rest -> col[] / w[] written in place, in edge-list order inside every row (stable, deterministic).
+// The scattered 4-byte stores of step 3 land in the bucket's own window of col[] (80 KB at config 3) from one workgroup, i.e. one
+// L2: they merge there and reach HBM as whole lines.  A bucket of any size is handled (the workgroup just loops longer), so the
+// result never depends on the edge distribution -- but a hub-heavy bucket serialises on its workgroup, which is why the host
+// side keeps the LSD build for skewed graphs (graph.py).
+constexpr int kBucketWaves = 8;
+#ifndef FSW_BUCKET_ROW_BITS
+#define FSW_BUCKET_ROW_BITS 11
+#endif
+constexpr int kBucketMaxRowBits = FSW_BUCKET_ROW_BITS;   // LDS: (kBucketWaves + 1) * 2^bits ints (72 KB at 11, 144 KB at 12)
+constexpr int kBucketAhead = 8;                          // rounds of 64 edges whose loads are in flight together
+
+template <class VAL>
+__global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint32_t* __restrict__ keys, const VAL* __restrict__ vals,
+                                                                      const int32_t* __restrict__ bstart, int64_t bstride, int ntable,
+                                                                      int64_t num_edges, int64_t num_rows, int rb,
+                                                                      int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                                      float* __restrict__ w) {
+  extern __shared__ int bsm[];   // wcnt[kBucketWaves][R] | tot[R]
+  const int R = 1 << rb;
+  const uint32_t rmask = (uint32_t)R - 1u;
+  int* wcnt = bsm;
+  int* tot = bsm + kBucketWaves * R;
+  __shared__ int wsum[kBucketWaves];
+  const int b = blockIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
+  const int64_t s = bstart[(int64_t)b * bstride];
+  const int64_t e = b + 1 < ntable ? (int64_t)bstart[(int64_t)(b + 1) * bstride] : num_edges;
+  for (int i = threadIdx.x; i < kBucketWaves * R; i += blockDim.x) wcnt[i] = 0;
+  __syncthreads();
+  // the wave's contiguous part of the bucket, a whole number of 64-edge rounds
+  const int64_t L = ceil_div(e - s, (int64_t)kBucketWaves * kWave) * kWave;
+  const int64_t w0 = min(s + wv * L, e), w1 = min(w0 + L, e);
+  int* mine = wcnt + wv * R;
+  for (int64_t i = w0 + lane; i < w1; i += kBucketAhead * kWave) {   // kBucketAhead loads in flight, then the LDS atomics
+    uint32_t kk[kBucketAhead];
+#pragma unroll
+    for (int u = 0; u < kBucketAhead; ++u) kk[u] = i + u * kWave < w1 ? keys[i + u * kWave] : 0u;
+#pragma unroll
+    for (int u = 0; u < kBucketAhead; ++u)
+      if (i + u * kWave < w1) atomicAdd(&mine[kk[u] & rmask], 1);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    int acc = 0;
+#pragma unroll
+    for (int q = 0; q < kBucketWaves; ++q) {
+      const int c = wcnt[q * R + r];
+      wcnt[q * R + r] = acc;
+      acc += c;
+    }
+    tot[r] = acc;
+  }
+  __syncthreads();
+  {  // exclusive scan of tot[0..R) in place: thread t owns R / blockDim.x consecutive rows
+    constexpr int kPerMax = (1 << kBucketMaxRowBits) / (kBucketWaves * kWave);
+    const int per = max(R / (int)blockDim.x, 1);
+    const int r0 = threadIdx.x * per;
+    int v[kPerMax], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPerMax; ++j) {
+      v[j] = (j < per && r0 + j < R) ? tot[r0 + j] : 0;
+      sum += v[j];
+    }
+    const int inc = wave_inclusive_scan(sum);
+    if (lane == kWave - 1) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < kBucketWaves; ++q)
+      if (q < wv) base += wsum[q];
+    int ex = base + inc - sum;
+#pragma unroll
+    for (int j = 0; j < kPerMax; ++j)
+      if (j < per && r0 + j < R) {
+        tot[r0 + j] = ex;
+        const int64_t row = (int64_t)b * R + r0 + j;
+        if (row <= num_rows) rowptr[row] = (int32_t)(s + ex);   // row == num_rows: the run of invalid edges (sentinel key) = nnz
+        ex += v[j];
+      }
+  }
+  __syncthreads();
+  for (int64_t g0 = w0; g0 < w1; g0 += kBucketAhead * kWave) {
+    uint32_t keyv[kBucketAhead];
+    VAL valv[kBucketAhead];
+#pragma unroll
+    for (int u = 0; u < kBucketAhead; ++u) {
+      const int64_t i = g0 + u * kWave + lane;
+      keyv[u] = i < w1 ? keys[i] : 0xffffffffu;
+      valv[u] = i < w1 ? vals[i] : VAL(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kBucketAhead; ++u) {
+      if (g0 + u * kWave >= w1) break;                       // wave-uniform
+      const bool ok = g0 + u * kWave + lane < w1;
+      const uint32_t key = keyv[u];
+      const uint32_t k = key & rmask;
+      unsigned long long peers = __ballot(ok);
+      if (!ok) peers = ~peers;
+#pragma unroll
+      for (int q = 0; q < kBucketMaxRowBits; ++q) {
+        if (q < rb) {
+          const unsigned long long bb = __ballot((k >> q) & 1u);
+          peers &= ((k >> q) & 1u) ? bb : ~bb;
+        }
+      }
+      const int leader = __ffsll((long long)peers) - 1;
+      const int below = __popcll(peers & ((1ull << lane) - 1ull));
+      int prev = 0;
+      if (ok && lane == leader) {
+        prev = mine[k];
+        mine[k] = prev + __popcll(peers);
+      }
+      prev = __shfl(prev, leader);
+      if (ok && (int64_t)key < num_rows) {
+        const int64_t pos = s + tot[k] + prev + below;
+        col[pos] = (int32_t)(uint32_t)valv[u];
+        if constexpr (sizeof(VAL) == 8) w[pos] = __uint_as_float((uint32_t)(valv[u] >> 32));
+      }
+    }
+  }
+}
+
+// first index of every bucket in the sorted keys (buckets = key >> rb): the multi-pass case of the two-level build
+__global__ void __launch_bounds__(256) k_bucket_starts(const uint32_t* __restrict__ keys, int64_t num_edges, int rb, int64_t nbuckets,
+                                                       int32_t* __restrict__ bstart) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= num_edges; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = i == 0 ? -1 : (int64_t)(keys[i - 1] >> rb);
+    const int64_t cur = i == num_edges ? nbuckets : (int64_t)(keys[i] >> rb);
+    for (int64_t q = prev + 1; q <= cur && q <= nbuckets; ++q) bstart[q] = (int32_t)i;
+  }
+}
+
+// shapes the two-level build is meant for: enough rows for a partition pass, buckets that one workgroup finishes quickly
+static bool two_level_ok(int64_t num_rows, int64_t num_edges) {
+  if (num_rows < (1 << 15) || num_edges < (1 << 18)) return false;
+  const int64_t nbuckets = ceil_div(num_rows + 1, (int64_t)1 << kBucketMaxRowBits);
+  return num_edges / nbuckets <= (1 << 16);
+}
+
+template <class VAL>
+static int sort_and_finish_two_level(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                                     int64_t num_rows, int64_t num_cols, int32_t* rowptr, int32_t* col, float* w, int32_t* stats,
+                                     GraphWs& g, hipStream_t stream) {
+  const int rb = std::min(kBucketMaxRowBits, key_bits(num_rows));
+  const int64_t nbuckets = ceil_div(num_rows + 1, (int64_t)1 << rb);
+  const int64_t ntiles = ceil_div(num_edges, kRsTile);
+  int cur = 0, bits = 0;
+  const int upper = key_bits(num_rows) - rb;
+  int rc = radix_sort_pairs<VAL, false>(recipients, senders, edge_w, false, num_edges, num_rows, num_cols, stats, g, &cur, stream, rb, 9, &bits);
+  if (rc) return rc;
+  const int32_t* bstart = g.counts;     // single pass: the scanned [digit][tile] table, digit = bucket
+  int64_t bstride = ntiles;
+  int ntable = 1 << bits;
+  if (bits != upper) {                  // several passes: bucket boundaries from the sorted keys
+    const int blocks = (int)std::min<int64_t>(ceil_div(num_edges + 1, 256), 256 * 32);
+    k_bucket_starts<<<blocks, 256, 0, stream>>>(g.keys[cur], num_edges, rb, nbuckets, g.block_sums_big);
+    FSW_LAUNCH_CHECK();
+    bstart = g.block_sums_big;
+    bstride = 1;
+    ntable = (int)nbuckets + 1;
+  }
+  const size_t lds = sizeof(int) * (size_t)(kBucketWaves + 1) * ((size_t)1 << rb);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(sizeof(int) * (kBucketWaves + 1) * (1 << kBucketMaxRowBits))));
+    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<unsigned long long>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(sizeof(int) * (kBucketWaves + 1) * (1 << kBucketMaxRowBits))));
+    attr_set = true;
+  }
+  k_bucket_rows<VAL><<<(unsigned)nbuckets, kBucketWaves * kWave, lds, stream>>>(g.keys[cur], reinterpret_cast<const VAL*>(g.vals[cur]), bstart,
+                                                                              bstride, ntable, num_edges, num_rows, rb, rowptr, col, w);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
 // keys = the sender of every CSR entry, values = the entry's position: the input of the sender-major sort (fsw_graph_transpose)
 __global__ void __launch_bounds__(256) k_entry_keys(const int32_t* __restrict__ col, int64_t nnz, int64_t num_cols,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -631,15 +827,14 @@ static int check_chunks(int64_t num_rows, int64_t chunk_rows) {
 using namespace fsw;
 
 extern "C" size_t fsw_graph_workspace_bytes(int64_t num_rows, int64_t num_edges) {
-  (void)num_rows;
-  GraphWs g = carve(nullptr, num_edges);
+  GraphWs g = carve(nullptr, num_edges, num_rows);
   return g.total;
 }
 
-extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
-                               int64_t num_rows, int64_t num_cols, int64_t chunk_rows, int32_t* rowptr, int32_t* col, float* w,
-                               int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
-                               size_t workspace_bytes, fsw_stream_t stream_) {
+static int graph_build_impl(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                            int64_t num_rows, int64_t num_cols, int64_t chunk_rows, int32_t* rowptr, int32_t* col, float* w,
+                            int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
+                            size_t workspace_bytes, fsw_stream_t stream_, bool two_level) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(num_rows >= 1 && num_rows < (1ll << 31) - 1 && num_cols >= 1 && num_cols < (1ll << 31) && num_edges >= 0 &&
                   num_edges < (1ll << 31) - kRsTile,
@@ -651,18 +846,40 @@ extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders
               "fsw_graph_build: null pointer");
   FSW_REQUIRE(!edge_w || w, "fsw_graph_build: edge_w given but w is null");
   if (int rc = check_chunks(num_rows, chunk_rows)) return rc;
-  GraphWs g = carve(workspace, num_edges);
+  GraphWs g = carve(workspace, num_edges, num_rows);
 
   FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, kBinTableBytes, stream));
   FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
   if (num_edges == 0) {
     FSW_CHECK_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)(num_rows + 1), stream));
+  } else if (two_level && two_level_ok(num_rows, num_edges)) {
+    int rc = edge_w ? sort_and_finish_two_level<unsigned long long>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream)
+                    : sort_and_finish_two_level<uint32_t>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream);
+    if (rc) return rc;
   } else {
     int rc = edge_w ? sort_and_finish<unsigned long long>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream)
                     : sort_and_finish<uint32_t>(recipients, senders, edge_w, num_edges, num_rows, num_cols, rowptr, col, w, stats, g, stream);
     if (rc) return rc;
   }
   return finish_bins(rowptr, num_rows, chunk_rows, perm, invperm, bin_start, stats, g, stream);
+}
+
+extern "C" int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                               int64_t num_rows, int64_t num_cols, int64_t chunk_rows, int32_t* rowptr, int32_t* col, float* w,
+                               int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
+                               size_t workspace_bytes, fsw_stream_t stream) {
+  return graph_build_impl(recipients, senders, edge_w, num_edges, num_rows, num_cols, chunk_rows, rowptr, col, w, perm, invperm, bin_start,
+                          stats, workspace, workspace_bytes, stream, false);
+}
+
+// Same contract and same result, bit for bit; the edges are grouped by a single partition pass + one workgroup per bucket of 2048
+// rows (above) when the shape suits that (>= 32768 rows, <= 65536 edges per bucket on average), by the LSD passes otherwise.
+extern "C" int fsw_graph_build_two_level(const int64_t* recipients, const int64_t* senders, const float* edge_w, int64_t num_edges,
+                                         int64_t num_rows, int64_t num_cols, int64_t chunk_rows, int32_t* rowptr, int32_t* col, float* w,
+                                         int32_t* perm, int32_t* invperm, int32_t* bin_start, int32_t* stats, void* workspace,
+                                         size_t workspace_bytes, fsw_stream_t stream) {
+  return graph_build_impl(recipients, senders, edge_w, num_edges, num_rows, num_cols, chunk_rows, rowptr, col, w, perm, invperm, bin_start,
+                          stats, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_t* senders, const float* edge_w,
@@ -679,7 +896,7 @@ extern "C" int fsw_graph_build_coalesced(const int64_t* recipients, const int64_
   FSW_REQUIRE(rowptr && perm && bin_start && stats && w && (num_edges == 0 || (col && recipients && senders)),
               "fsw_graph_build_coalesced: null pointer");
   FSW_REQUIRE(d_edge >= 0 && (d_edge == 0 || (edge_feat && ef)), "fsw_graph_build_coalesced: edge features need edge_feat and ef");
-  GraphWs g = carve(workspace, num_edges);
+  GraphWs g = carve(workspace, num_edges, num_rows);
   FSW_CHECK_HIP(hipMemsetAsync(g.bin_count, 0, kBinTableBytes, stream));
   FSW_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(int32_t) * FSW_NUM_STATS, stream));
   if (num_edges == 0) {
@@ -734,7 +951,7 @@ extern "C" int fsw_graph_transpose(const int32_t* col, int64_t nnz, int64_t num_
     FSW_CHECK_HIP(hipMemsetAsync(cptr, 0, sizeof(int32_t) * (size_t)(num_cols + 1), stream));
     return 0;
   }
-  GraphWs g = carve(workspace, nnz);
+  GraphWs g = carve(workspace, nnz, num_cols);
   const int blocks = (int)std::min<int64_t>(ceil_div(nnz + 1, 256), 256 * 32);
   k_entry_keys<<<blocks, 256, 0, stream>>>(col, nnz, num_cols, g.keys[0], reinterpret_cast<uint32_t*>(g.vals[0]));
   FSW_LAUNCH_CHECK();

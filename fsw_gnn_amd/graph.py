@@ -51,6 +51,8 @@ class CSRGraph:
     def read_stats(self):
         """Fresh host copy of the stats words (one small device->host copy; synchronises the stream)."""
         self._stats = self.stats_dev.cpu().tolist()
+        if self._stats[_lib.STAT_MAX_DEGREE] > TWO_LEVEL_MAX_DEGREE:
+            _skewed_shapes.add((self.num_rows, self.num_edges))
         return self._stats
 
     def stats(self):
@@ -82,9 +84,17 @@ def round_chunk_rows(rows, multiple_of=1):
     return max(1, -(-int(rows) // m)) * m
 
 
-def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False, chunk_rows=0):
+# Shapes (rows, edges) whose last build showed hub rows: the two-level build (one workgroup per bucket of 2048 rows) would
+# serialise on the hubs' buckets, so those shapes go back to the LSD passes.  Both builds give the same CSR, entry for entry.
+_skewed_shapes = set()
+TWO_LEVEL_MAX_DEGREE = 2048
+
+
+def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False, chunk_rows=0, algo="auto"):
     """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights).
-    chunk_rows > 0: degree bins per chunk of chunk_rows consecutive rows (include/fsw_hip.h, fsw_graph_build)."""
+    chunk_rows > 0: degree bins per chunk of chunk_rows consecutive rows (include/fsw_hip.h, fsw_graph_build).
+    algo: 'lsd' (fsw_graph_build), 'two_level' (fsw_graph_build_two_level), or 'auto' = two_level unless the last graph of this
+    shape had a row above TWO_LEVEL_MAX_DEGREE neighbours (noted when its stats are read)."""
     L = _lib.lib()
     dev = recipients.device
     if dev.type != "cuda":
@@ -109,9 +119,12 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = L.fsw_graph_build(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols, chunk_rows,
-                           _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
-                           _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
+    assert algo in ("auto", "lsd", "two_level")
+    two_level = algo == "two_level" or (algo == "auto" and (num_rows, E) not in _skewed_shapes)
+    fn = L.fsw_graph_build_two_level if two_level else L.fsw_graph_build
+    rc = fn(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols, chunk_rows,
+            _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
+            _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
     return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start if chunk_rows else bin_start.view(-1), stats, invperm,
                     chunk_rows=chunk_rows)

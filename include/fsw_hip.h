@@ -111,6 +111,14 @@ int fsw_graph_build(const int64_t* recipients, const int64_t* senders, const flo
                     int64_t num_edges, int64_t num_rows, int64_t num_cols, int64_t chunk_rows,
                     int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* invperm, int32_t* bin_start,
                     int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
+/* The same build with the same arguments and the same result, entry for entry; one partition pass over the high row bits +
+ * one workgroup per bucket of 2048 rows instead of three LSD passes when the shape suits it (>= 32768 rows, <= 65536 edges
+ * per bucket on average; the LSD passes otherwise).  Faster on graphs without hub rows (0.38 -> ~0.2 ms at 1M rows / 10M
+ * edges); a bucket that holds hub rows serialises on its workgroup, so callers keep fsw_graph_build for skewed graphs.   */
+int fsw_graph_build_two_level(const int64_t* recipients, const int64_t* senders, const float* edge_w,
+                    int64_t num_edges, int64_t num_rows, int64_t num_cols, int64_t chunk_rows,
+                    int32_t* rowptr, int32_t* col, float* w, int32_t* perm, int32_t* invperm, int32_t* bin_start,
+                    int32_t* stats, void* workspace, size_t workspace_bytes, fsw_stream_t stream);
 
 /* Coalescing variant: entries sorted by (recipient, sender), parallel edges merged into ONE entry whose
  * weight (edge_w or 1 per edge) and edge-feature vector are the sums over the duplicates -- exactly what

@@ -102,6 +102,53 @@ def test_graph_build_matches_oracle_adjacency(dev):
     assert gr2.flags & 1
 
 
+@pytest.mark.parametrize("rows,edges,weighted,bad", [
+    (200_000, 1_000_000, False, 0),       # one partition pass (7 upper bits), 98 buckets
+    (65_535, 400_000, True, 17),          # rows + 1 (the sentinel) starts a bucket of its own; weights; invalid edges
+    (70_001, 300_000, False, 5),          # last bucket partly filled, invalid edges share it with valid rows
+    (3_000_000, 2_000_000, False, 0),     # 11 upper bits: two partition passes, bucket starts from the sorted keys
+    (100_000, 600_000, True, 0),
+])
+def test_two_level_graph_build_equals_lsd_build(dev, rows, edges, weighted, bad):
+    """fsw_graph_build_two_level (partition pass + one workgroup per bucket of 2048 rows) against fsw_graph_build (three LSD
+    passes): the same rowptr / col / w / perm / bin_start / stats, entry for entry, including a hub row and out-of-range
+    edges (which both builds drop and flag)."""
+    from fsw_gnn_amd import build_csr
+    g = torch.Generator(device="cpu").manual_seed(rows + edges)
+    rec = torch.randint(0, rows, (edges,), generator=g)
+    snd = torch.randint(0, rows, (edges,), generator=g)
+    rec[:5000] = 12345                                    # a hub row: 5000 edges in one bucket
+    if bad:
+        idx = torch.randint(0, edges, (bad,), generator=g)
+        rec[idx[: bad // 2]] = rows + 3
+        snd[idx[bad // 2:]] = -1
+    w = (torch.rand(edges, generator=g) + 0.01) if weighted else None
+    rec, snd = rec.to(dev), snd.to(dev)
+    wd = None if w is None else w.to(dev)
+    a = build_csr(rec, snd, wd, rows, rows, want_invperm=True, algo="lsd")
+    b = build_csr(rec, snd, wd, rows, rows, want_invperm=True, algo="two_level")
+    sa, sb = a.stats_dev.cpu().tolist(), b.stats_dev.cpu().tolist()
+    assert sa == sb, (sa, sb)
+    nnz = sa[6]
+    assert nnz == edges - bad and bool(sa[0] & 1) == bool(bad)
+    assert torch.equal(a.rowptr, b.rowptr)
+    assert torch.equal(a.col[:nnz], b.col[:nnz])
+    if weighted:
+        assert torch.equal(a.w[:nnz], b.w[:nnz])
+    assert torch.equal(a.bin_start, b.bin_start)
+    # perm lists every bin's rows in an order that depends on atomics between workgroups: compare as sets per bin
+    bs = a.bin_start.cpu().tolist()
+    pa, pb = a.perm.cpu(), b.perm.cpu()
+    for lo, hi in zip(bs[:-1], bs[1:]):
+        if hi > lo:
+            assert torch.equal(torch.sort(pa[lo:hi]).values, torch.sort(pb[lo:hi]).values)
+    # and against torch: stable sort by recipient
+    ok = (rec >= 0) & (rec < rows) & (snd >= 0) & (snd < rows)
+    order = torch.sort(rec[ok], stable=True).indices
+    assert torch.equal(b.col[:nnz].long(), snd[ok][order])
+    assert torch.equal(b.rowptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(rec[ok], minlength=rows).cumsum(0)]))
+
+
 def test_tiny_graph_all_variants(dev):
     g = golden("tiny_graph")
     X = t(g["X"], dev)
