@@ -39,6 +39,7 @@ class EmbedArgs(ctypes.Structure):
         ("max_degree", c_i64),
         ("scratch", c_vp), ("scratch_bytes", c_sz),
         ("efeat", c_vp), ("Ve", c_vp), ("ldve", c_i64), ("d_edge", c_i32), ("reserved", c_i32),
+        ("bin_start_host", c_vp),
     ]
 
 

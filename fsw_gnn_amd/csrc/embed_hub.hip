@@ -304,6 +304,7 @@ __global__ void __launch_bounds__(kGiantNW* kWave, 4) k_embed_giant(const int32_
 
 // unit weights, tau <= 1: the rows above FSW_HUB_MAX_DEG.  scratch: fsw_embed_scratch_bytes(max_degree).
 int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  rows_upper = bin_rows_or(a, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL, rows_upper);
   if (rows_upper <= 0 || (a.max_degree > 0 && a.max_degree <= FSW_HUB_MAX_DEG)) return 0;
   FSW_REQUIRE(a.max_degree > FSW_HUB_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_HUB_MAX_DEG");
   FSW_REQUIRE(a.scratch, "fsw_embed_f32: rows above FSW_HUB_MAX_DEG need a scratch buffer (fsw_embed_scratch_bytes)");
@@ -323,6 +324,8 @@ int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t 
 template <int NW, int M>
 static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
   constexpr int LPB = NW == 1 ? 4 : 1;
+  rows_upper = bin_rows_or(a, bin, bin, rows_upper);   // exact when the host knows the bins: an empty bin is not launched
+  if (rows_upper <= 0) return 0;
   // virtual blocks = (rows rounded up to 8) x slices / lines per block; the launched grid is capped at 2^20 workgroups
   // (a dispatch holds < 2^32 work-items: 17.7M x 256 threads were silently truncated on a 64M-edge graph) and strides
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;

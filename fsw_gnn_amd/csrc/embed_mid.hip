@@ -173,11 +173,13 @@ int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream
 int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
 
 #define FSW_MID_UNIT(i, DP)                                                                                               \
+  if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0)                                                            \
   k_embed_mid_unit<DP><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S,  \
                                                  a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,       \
                                                  a.mass_scale);                                                           \
   FSW_LAUNCH_CHECK()
 #define FSW_MID_WEIGHTED(i, DP)                                                                                           \
+  if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0)                                                            \
   k_embed_mid_weighted<DP + 1><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp,  \
                                                          a.ldp, a.S, a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale,   \
                                                          a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve,      \

@@ -49,6 +49,11 @@ __host__ __device__ inline int degree_bin(int deg) {
   return FSW_BIN_MID0 + i;
 }
 
+// rows of the degree bins lo .. hi when the caller passed the host copy of bin_start, `upper` (a bound) otherwise
+inline int64_t bin_rows_or(const fsw_embed_args& a, int lo, int hi, int64_t upper) {
+  return a.bin_start_host ? (int64_t)a.bin_start_host[hi + 1] - a.bin_start_host[lo] : upper;
+}
+
 __host__ __device__ inline uint32_t pow2ceil(uint32_t v) {
   uint32_t p = 1;
   while (p < v) p <<= 1;

@@ -778,6 +778,9 @@ class FSW_embedding(nn.Module):
             a.bin_start = graph.bin_start.view(-1, _lib.NUM_BINS + 1)[chunk].data_ptr()
             rows = min(graph.chunk_rows, graph.num_rows - chunk * graph.chunk_rows) if graph.chunk_rows else graph.num_rows
         a.num_rows = rows
+        bsh = getattr(graph, "bin_start_host", None)     # host copy of the bin table (read with the stats): exact grids
+        if bsh is not None:
+            a.bin_start_host = bsh[0 if chunk is None else chunk].ctypes.data
         a.Xp, a.ldp, a.freqs, a.S, a.tau = Xp.data_ptr(), ldp, freqs.data_ptr(), S, float(self.total_mass_pad_thresh)
         a.unit_table, a.ldt = (table.data_ptr() if table is not None else None), ldp
         a.out, a.ldo, a.bias = out_ptr, ldo, bias_ptr

@@ -18,7 +18,7 @@ class CSRGraph:
     """
 
     def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None, ef=None,
-                 slot_of_edge=None, chunk_rows=0):
+                 slot_of_edge=None, chunk_rows=0, meta=None):
         self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
         # chunk_rows > 0: bin_start is [num_chunks, NUM_BINS + 1], rows binned per chunk of chunk_rows consecutive rows
         self.chunk_rows = chunk_rows
@@ -30,6 +30,8 @@ class CSRGraph:
         self.slot_of_edge = slot_of_edge    # int32[num_input_edges]: CSR entry of every input edge (coalesced build)
         self._stats = None
         self._sender_major = None
+        self._meta = meta                   # int32 [NUM_STATS + num_chunks * (NUM_BINS + 1)]: stats_dev | bin_start, or None
+        self.bin_start_host = None          # numpy int32 [num_chunks, NUM_BINS + 1] after read_stats()
 
     def sender_major(self):
         """(cptr int32[num_cols + 1], order int32[nnz]): the CSR entries listed sender by sender (fsw_graph_transpose), built on
@@ -50,7 +52,14 @@ class CSRGraph:
 
     def read_stats(self):
         """Fresh host copy of the stats words (one small device->host copy; synchronises the stream)."""
-        self._stats = self.stats_dev.cpu().tolist()
+        if self._meta is not None:
+            # stats and the bin table live in one buffer: ONE device->host copy brings both (the library sizes its grids by
+            # the exact rows of every degree bin when it gets the host table: fsw_embed_args.bin_start_host)
+            host = self._meta.cpu().numpy()
+            self._stats = host[:_lib.NUM_STATS].tolist()
+            self.bin_start_host = host[_lib.NUM_STATS:].reshape(self.num_chunks, _lib.NUM_BINS + 1)
+        else:
+            self._stats = self.stats_dev.cpu().tolist()
         if self._stats[_lib.STAT_MAX_DEGREE] > TWO_LEVEL_MAX_DEGREE:
             _skewed_shapes.add((self.num_rows, self.num_edges))
         return self._stats
@@ -114,8 +123,8 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     invperm = torch.empty(num_rows, dtype=torch.int32, device=dev) if want_invperm else None
     num_chunks = -(-num_rows // chunk_rows) if chunk_rows else 1
     assert num_chunks <= _lib.MAX_ROW_CHUNKS and chunk_rows % _lib.BIN_BLOCK_ROWS == 0, "bad chunk_rows"
-    bin_start = torch.empty((num_chunks, _lib.NUM_BINS + 1), dtype=torch.int32, device=dev)
-    stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
+    meta = torch.empty(_lib.NUM_STATS + num_chunks * (_lib.NUM_BINS + 1), dtype=torch.int32, device=dev)
+    stats, bin_start = meta[:_lib.NUM_STATS], meta[_lib.NUM_STATS:].view(num_chunks, _lib.NUM_BINS + 1)
     ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -127,7 +136,7 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
             _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
     return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start if chunk_rows else bin_start.view(-1), stats, invperm,
-                    chunk_rows=chunk_rows)
+                    chunk_rows=chunk_rows, meta=meta)
 
 
 def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_cols, want_slots=False):
@@ -157,8 +166,8 @@ def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_co
     ef = torch.empty((max(E, 1), d_edge), dtype=torch.float32, device=dev) if d_edge else None
     slot = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_slots else None
     perm = torch.empty(num_rows, dtype=torch.int32, device=dev)
-    bin_start = torch.empty(_lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
-    stats = torch.empty(_lib.NUM_STATS, dtype=torch.int32, device=dev)
+    meta = torch.empty(_lib.NUM_STATS + _lib.NUM_BINS + 1, dtype=torch.int32, device=dev)
+    stats, bin_start = meta[:_lib.NUM_STATS], meta[_lib.NUM_STATS:]
     ws_bytes = L.fsw_graph_workspace_bytes(num_rows, E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -166,4 +175,4 @@ def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_co
                                      num_rows, num_cols, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(ef), _lib.ptr(slot),
                                      _lib.ptr(perm), None, _lib.ptr(bin_start), _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build_coalesced")
-    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, None, ef, slot)
+    return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start, stats, None, ef, slot, meta=meta)

@@ -195,6 +195,10 @@ typedef struct {
   int64_t ldve;
   int32_t d_edge;
   int32_t reserved;
+  /* HOST copy of the FSW_NUM_BINS + 1 words bin_start points at (nullable): with it the library knows the rows of every
+   * degree bin -- empty bins are not launched and every grid is sized exactly (without it the grids are sized by the class
+   * totals above and surplus workgroups leave at once: 4.5 of 81 ms on a 64M-edge RMAT graph).            */
+  const int32_t* bin_start_host;
 } fsw_embed_args;
 
 size_t fsw_embed_scratch_bytes(int64_t max_degree);

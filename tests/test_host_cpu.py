@@ -58,7 +58,7 @@ def test_embed_args_struct_matches_header_layout():
         names.append(re.findall(r"[A-Za-z_0-9]+", first)[-1])
         names += [re.findall(r"[A-Za-z_0-9]+", r)[-1] for r in rest]
     assert names == [f[0] for f in _lib.EmbedArgs._fields_]
-    assert ctypes.sizeof(_lib.EmbedArgs) == 8 * 6 + 8 * 3 + 8 + 8 * 2 + 8 * 3 + 16 + 8 * 5 + 16 + 8 * 3 + 8
+    assert ctypes.sizeof(_lib.EmbedArgs) == 8 * 6 + 8 * 3 + 8 + 8 * 2 + 8 * 3 + 16 + 8 * 5 + 16 + 8 * 3 + 8 + 8
 
 
 def test_sorting_networks_native():
