@@ -127,6 +127,22 @@ __device__ __forceinline__ void gather_chunk(WaveLine<M, false>& ln, const int32
     ln.k[j] = c[j] >= 0 ? ((FSW_HUB_ABL & 1) ? (float)((c[j] * 2654435761u) >> 8) : Xp[(int64_t)c[j] * ldp + k]) : __builtin_inff();
 }
 
+// one line: gather, sort inside the wavefronts, merge across them, readout.  Returns the wavefront's partial sum.
+template <int NW, int M>
+__device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, int D, const float* __restrict__ Xp, int64_t ldp, int k,
+                                          float xif, float* __restrict__ xbuf, int w, int lane) {
+  constexpr int CAP = M * kWave;
+  WaveLine<M, false> ln;
+  gather_chunk<M>(ln, colrow, w * CAP, D, Xp, ldp, k, lane);
+  if (!(FSW_HUB_ABL & 2)) ln.sort();
+  if constexpr (NW > 1) workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
+  return wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, xif));
+}
+
+#ifndef FSW_HUB_SPLIT
+#define FSW_HUB_SPLIT 1   // 0: every line on the full class size (for comparison)
+#endif
+
 // NW wavefronts per line, M keys per lane; NW == 1: the workgroup is four independent wavefronts on four lines (adjacent
 // slices of one row) and never synchronises -- the wave-sort classes 257..2048 (M = 8 / 16 / 32) run this way
 template <int NW, int M>
@@ -156,11 +172,15 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
 
-    WaveLine<M, false> ln;
-    gather_chunk<M>(ln, col + start, w * CAP, D, Xp, ldp, k, lane);
-    if (!(FSW_HUB_ABL & 2)) ln.sort();
-    if constexpr (NW > 1) workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
-    float tot = wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, freqs[k]));
+    // one wavefront per line: a line of at most 3/4 of the class size runs on 3/4 of the keys per lane (24 / 12 / 6) -- the same
+    // network, a quarter fewer comparators; rows spread over (2^k, 2^(k+1)], so about half of them qualify (wave-uniform
+    // branch).  Measured on the 64M-edge RMAT graph: class 1025..2048 13.2 -> 11.6 ms.  The multi-wavefront classes gain
+    // nothing from it (4097..8192: 12.3 ms either way -- they wait on the exchange barriers, not on comparators) and the
+    // second code path costs them registers (20..50 spilled), so they always run the full size.
+    constexpr int MS = (M * 3) / 4;
+    float tot;
+    if (FSW_HUB_SPLIT && NW == 1 && D <= kWave * MS) tot = hub_line<NW, MS>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
+    else tot = hub_line<NW, M>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
     if constexpr (NW > 1) {
       if (lane == 0) red[w] = tot;
       __syncthreads();

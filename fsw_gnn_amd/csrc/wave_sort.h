@@ -119,11 +119,7 @@ struct WaveLine {
     if constexpr (LANES <= kWave) {
       exchange<1, LANES - 1>((lane & (LANES >> 1)) == 0);          // element i against i ^ (LANES*M - 1)
       half_cleaners<(LANES >> 2)>(lane);
-#pragma unroll
-      for (int st = M >> 1; st >= 1; st >>= 1)
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-          if ((j & st) == 0) cx(j, j + st);
+      in_register_merge<M, 0>();
       merge_levels<LANES * 2>(lane);
     }
   }
@@ -131,11 +127,25 @@ struct WaveLine {
   __device__ __forceinline__ void merge_chunk() {
     const int lane = lane_id();
     half_cleaners<(kWave >> 1)>(lane);
+    in_register_merge<M, 0>();
+  }
+  // bitonic merge of the lane's registers BASE .. BASE + LEN - 1 (a bitonic sequence): half-cleaners while the length is even,
+  // a 3-sorter for an odd remainder -- M = 32 / 16 / 8 are the classic log2(M) stages, M = 24 / 12 / 6 (lines of 1.5 x a
+  // power of two) halve down to groups of three
+  template <int LEN, int BASE>
+  __device__ __forceinline__ void in_register_merge() {
+    if constexpr (LEN >= 2 && LEN % 2 == 0) {
 #pragma unroll
-    for (int st = M >> 1; st >= 1; st >>= 1)
-#pragma unroll
-      for (int j = 0; j < M; ++j)
-        if ((j & st) == 0) cx(j, j + st);
+      for (int j = 0; j < LEN / 2; ++j) cx(BASE + j, BASE + j + LEN / 2);
+      in_register_merge<LEN / 2, BASE>();
+      in_register_merge<LEN / 2, BASE + LEN / 2>();
+    } else if constexpr (LEN == 3) {
+      cx(BASE, BASE + 1);
+      cx(BASE + 1, BASE + 2);
+      cx(BASE, BASE + 1);
+    } else {
+      static_assert(LEN == 1, "keys per lane: a power of two, or three times one");
+    }
   }
   template <int ST>
   __device__ __forceinline__ void half_cleaners(int lane) {

@@ -15,7 +15,7 @@ if [ "$1" = build ]; then
     for o in $src/_build/*.o; do
       f=$(basename $o .o)
       case "$f" in
-        embed_reg|conv_fused|project|graph_build|embed_wsort|embed_wsort_bwd) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -c $src/$f.hip -o $o ;;
+        embed_reg|conv_fused|project|graph_build|embed_wsort|embed_wsort_bwd|embed_hub) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -c $src/$f.hip -o $o ;;
         embed_mid|embed_lds) continue ;;   # stale objects of removed / split sources
       esac
       objs="$objs $o"
