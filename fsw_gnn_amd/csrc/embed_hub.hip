@@ -80,8 +80,8 @@ __device__ __forceinline__ void workgroup_merge_block(WaveLine<M, false>& ln, fl
 // unit-weight readout of the lane's M keys of ranks r0 .. r0 + M - 1 in a neighbourhood of D: coefficients
 // (1 + xi) [sin(2 pi xi (r + 1) / D) - sin(2 pi xi r / D)] / (pi xi) (reference fsw_embedding.py:1047-1075, 1109 with
 // weights 1 / D) by a float64 rotation started at the lane's first rank.  Returns the lane's partial sum.
-template <int M>
-__device__ __forceinline__ float unit_readout(const WaveLine<M, false>& ln, int r0, int D, float xif) {
+template <int M, class Line>
+__device__ __forceinline__ float unit_readout(const Line& ln, int r0, int D, float xif) {
   const double xi = (double)xif;
   const double inv = 1.0 / (double)D;
   float acc = 0.f;
@@ -139,6 +139,9 @@ __device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, in
   return wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, xif));
 }
 
+#ifndef FSW_HUB_ROWLINES
+#define FSW_HUB_ROWLINES 1   // 0: class 257..512 as one 64-lane line of 8 keys per lane (for comparison)
+#endif
 #ifndef FSW_HUB_SPLIT
 #define FSW_HUB_SPLIT 1   // 0: every line on the full class size (for comparison)
 #endif
@@ -357,6 +360,67 @@ static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipS
   return 0;
 }
 
+
+// ---- 257..512 neighbours: FOUR lines per wavefront, one per row of 16 lanes x 32 keys -----------------------------------------
+// With 16 lanes per line every cross-lane exchange of the merge levels is one DPP move inside a row (10 exchanges instead of the
+// 21 of a 64-lane line; the in-register part grows from 8 to 32 keys per lane, where a comparator costs one instruction per
+// key instead of two): ~0.8 instead of ~1.2 instructions per key.  The four lines are four adjacent slices of one row, so a
+// gather instruction reads 16 bytes from each of 16 rows of Xp instead of 4 bytes from 64.
+constexpr int kRowLanes = 16;
+constexpr int kRowM = 32;
+
+__global__ void __launch_bounds__(256, 4) k_embed_rowlines(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start, int bin,
+                                                           const float* __restrict__ Xp, int64_t ldp, int S, const float* __restrict__ freqs,
+                                                           float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
+                                                           float out_scale, int has_mass, int mass_fn, float mass_scale) {
+  constexpr int M = kRowM, LPW = kWave / kRowLanes, LPB = 4 * LPW;   // lines per wavefront / per block
+  const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
+  const int lane = lane_id(), sub = lane & (kRowLanes - 1);
+  const int xcd = blockIdx.x & 7;
+  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
+    const int64_t i = (vb >> 3) * LPB + wave_id() * LPW + (lane >> 4);
+    const int64_t rl = i / S;
+    const int k = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;          // per row of 16 lanes; nothing below synchronises or crosses rows
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    WaveLine<M, false, false, kRowLanes> ln;
+    const int32_t* colrow = col + start;
+    int c[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int t = j * kRowLanes + sub;
+      c[j] = t < D ? colrow[t] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) ln.k[j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
+    ln.sort();
+    float tot = unit_readout<M>(ln, sub * M, D, freqs[k]);
+#pragma unroll
+    for (int off = kRowLanes / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (sub == 0) {
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
+static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
+  constexpr int LPB = 4 * (kWave / kRowLanes);
+  rows_upper = bin_rows_or(a, bin, bin, rows_upper);
+  if (rows_upper <= 0) return 0;
+  const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
+  const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
+  k_embed_rowlines<<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo,
+                                                         a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
 // unit weights, tau <= 1: rows of the four hub bins.  rows_upper bounds the rows above FSW_LDS_MAX_DEG (the per-bin counts
 // stay on the device: surplus blocks exit at once).
 int launch_embed_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
@@ -376,7 +440,9 @@ int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_
   if (rows_upper <= 0) return 0;
   int rc;
   const int64_t md = a.max_degree;
-  if ((md <= 0 || md > FSW_MID_MAX_DEG) && (rc = launch_hub<1, 8>(a, FSW_BIN_LDS0, rows_upper, stream))) return rc;
+  if ((md <= 0 || md > FSW_MID_MAX_DEG) &&
+      (rc = FSW_HUB_ROWLINES ? launch_rowlines(a, FSW_BIN_LDS0, rows_upper, stream) : launch_hub<1, 8>(a, FSW_BIN_LDS0, rows_upper, stream)))
+    return rc;
   if ((md <= 0 || md > 512) && (rc = launch_hub<1, 16>(a, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;
   if ((md <= 0 || md > 1024) && (rc = launch_hub<1, 32>(a, FSW_BIN_LDS0 + 2, rows_upper, stream))) return rc;
   return 0;

@@ -40,7 +40,9 @@ __device__ __forceinline__ float minmax_by_limit(float a, float b, float lim) { 
 // keys (and weights) of one line across the wave, blocked layout; ascending over element index l*M + j afterwards
 // TIEBREAK: the payload is the element index and equal keys are ordered by it (= a stable sort by key, the order the
 // reference's sort and the oracle produce; the backward kernels need it to hand tied neighbours the same coefficients)
-template <int M, bool WEIGHTED, bool TIEBREAK = false>
+// LL: lanes per line (64: one line across the wavefront; 16: four independent lines, one per DPP row -- every exchange of its
+// merge levels is then a single DPP move)
+template <int M, bool WEIGHTED, bool TIEBREAK = false, int LL = kWave>
 struct WaveLine {
   float k[M];
   float w[WEIGHTED ? M : 1];
@@ -116,7 +118,7 @@ struct WaveLine {
   // compile-time constant, so the compiler can use DPP / swizzles for the short ones)
   template <int LANES>
   __device__ __forceinline__ void merge_levels(int lane) {
-    if constexpr (LANES <= kWave) {
+    if constexpr (LANES <= LL) {
       exchange<1, LANES - 1>((lane & (LANES >> 1)) == 0);          // element i against i ^ (LANES*M - 1)
       half_cleaners<(LANES >> 2)>(lane);
       in_register_merge<M, 0>();
