@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(768) k_project_bs(const float* __restrict__ X,
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // bf16 per LDS row of the A planes: 16 KS + 8 (16-byte pad: row stride = 4 banks mod 64, conflict-free 16-byte fragment reads)
+#ifndef FSW_PROJECT_DIRECT_C
+#define FSW_PROJECT_DIRECT_C 0   // 1: C tile stored straight from the accumulators instead of through the LDS staging tile
+#endif
 #ifndef FSW_PROJECT_ABL
 #define FSW_PROJECT_ABL 0   // timing experiments (tools/exp_variants.sh): 1 = no MFMA, 2 = no output stores
 #endif
@@ -426,12 +429,29 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
       }
+#if FSW_PROJECT_DIRECT_C
+      // straight from the accumulators: every store instruction covers two rows x 32 columns = two whole 128-byte lines
+      if (col_ok && !(FSW_PROJECT_ABL & 2)) {
+        const int64_t row0 = tile * BS_ROWS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int R = (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
+          if (row0 + R < n) {
+            if (second) Y2[(int64_t)rmap[buf * BS_ROWS + R] * ldy2 + c] = acc[r] + add;
+            else Xp[(row0 + R) * ldp + c] = acc[r] + add;
+          }
+        }
+      }
+#else
       float* cs = Cs + buf * BS_ROWS * ldc + wv * 32 + fr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
+#endif
     }
     __syncthreads();
+#if !FSW_PROJECT_DIRECT_C
     if (!(FSW_PROJECT_ABL & 2)) write_out(buf, tile);
+#endif
     buf ^= 1;
   }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
