@@ -147,6 +147,12 @@ def test_two_level_graph_build_equals_lsd_build(dev, rows, edges, weighted, bad)
     order = torch.sort(rec[ok], stable=True).indices
     assert torch.equal(b.col[:nnz].long(), snd[ok][order])
     assert torch.equal(b.rowptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(rec[ok], minlength=rows).cumsum(0)]))
+    # row chunks (the multi-GPU pipeline bins the rows per chunk): the same tables from both builds
+    if rows == 200_000:
+        ca = build_csr(rec, snd, wd, rows, rows, want_invperm=True, chunk_rows=65536, algo="lsd")
+        cb = build_csr(rec, snd, wd, rows, rows, want_invperm=True, chunk_rows=65536, algo="two_level")
+        assert ca.num_chunks == 4 and torch.equal(ca.bin_start, cb.bin_start) and torch.equal(ca.col[:nnz], cb.col[:nnz])
+        assert torch.equal(torch.sort(ca.perm).values, torch.sort(cb.perm).values)
 
 
 def test_tiny_graph_all_variants(dev):
