@@ -351,7 +351,9 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(const float* __restric
   const int k = chunk * kWave + lane_id();
   const bool kvalid = k < S;
   const int kc = kvalid ? k : S - 1;
-  const int64_t q0 = (int64_t)blockIdx.x * kSegLen, q1 = min(q0 + kSegLen, nnz);
+  // entries past ptr[num_out] belong to no sender (fsw_graph_transpose sorts out-of-range columns there): never walked
+  const int64_t q0 = (int64_t)blockIdx.x * kSegLen, q1 = min(q0 + kSegLen, min(nnz, (int64_t)ptr[num_out]));
+  if (q0 >= q1) return;
   // sender of entry q0: the largest j with ptr[j] <= q0 (wave-uniform binary search)
   int64_t lo = 0, hi = num_out;
   while (hi - lo > 1) {

@@ -63,9 +63,17 @@ __global__ void __launch_bounds__(256) k_zero_rows(const int32_t* __restrict__ p
   const int p0 = bin_start[0], n0 = bin_start[1] - p0;
   const int width = S + has_mass;
   const int wave = blockIdx.x * (blockDim.x / kWave) + wave_id(), nwaves = gridDim.x * (blockDim.x / kWave);
-  for (int i = wave; i < n0; i += nwaves) {
-    float* orow = out + (int64_t)perm[p0 + i] * ldo;
-    for (int c = lane_id(); c < width; c += kWave) orow[c] = bias ? out_scale * bias[c] : 0.f;
+  // four rows per step: their perm entries are loaded together, so four rows' stores are in flight instead of one row's
+  for (int i = wave * 4; i < n0; i += nwaves * 4) {
+    int node[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) node[u] = i + u < n0 ? perm[p0 + i + u] : -1;
+    for (int c = lane_id(); c < width; c += kWave) {
+      const float v = bias ? out_scale * bias[c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (node[u] >= 0) out[(int64_t)node[u] * ldo + c] = v;
+    }
   }
 }
 
@@ -250,7 +258,7 @@ int launch_unit_table(const float* freqs, int S, int max_deg, float* table, int6
 }
 
 int launch_zero_rows(const fsw_embed_args& a, hipStream_t stream) {
-  k_zero_rows<<<1024, 256, 0, stream>>>(a.perm, a.bin_start, a.S, a.out, a.ldo, a.bias, a.out_scale, a.has_mass);
+  k_zero_rows<<<2048, 256, 0, stream>>>(a.perm, a.bin_start, a.S, a.out, a.ldo, a.bias, a.out_scale, a.has_mass);
   FSW_LAUNCH_CHECK();
   return 0;
 }
