@@ -113,6 +113,26 @@ static int exclusive_scan_i32(int32_t* data, int64_t n, int32_t* block_sums, hip
   return 0;
 }
 
+// Lanes of the wavefront whose digit equals this lane's (wave64 "match any" from one ballot per digit bit).  The lanes that
+// differ from me in some bit are accumulated in two 32-bit halves -- per bit one v_bfe, one v_cmp and two or/xor pairs, no
+// 64-bit selects and no branches (bits above the digit width are zero in every lane and change nothing).  Inactive lanes
+// (ok == false) form a group of their own.
+template <int MAXB>
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool ok) {
+  uint32_t dlo = 0u, dhi = 0u;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const uint32_t bit = (d >> b) & 1u;
+    const unsigned long long bb = __ballot(bit != 0u);
+    const uint32_t m = 0u - bit;
+    dlo |= (uint32_t)bb ^ m;
+    dhi |= (uint32_t)(bb >> 32) ^ m;
+  }
+  const unsigned long long okm = __ballot(ok);
+  const unsigned long long same = ~(((unsigned long long)dhi << 32) | (unsigned long long)dlo);
+  return ok ? (same & okm) : ~okm;
+}
+
 // ---- radix sort by recipient ----------------------------------------------------------------------------
 // Key of edge e: its recipient, or `num_rows` (a sentinel that sorts last) when an endpoint is out of range.
 template <bool FIRST>
@@ -145,18 +165,27 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_upsweep(const int64_t* __rest
   const int64_t tile0 = (int64_t)blockIdx.x * kRsTile;
   const uint32_t mask = (uint32_t)ndigits - 1;
   int flags = 0;
-#pragma unroll 4
-  for (int i = 0; i < kRsItems; ++i) {
-    const int64_t e = tile0 + (int64_t)i * kRsThreads + threadIdx.x;
-    if (e < num_edges) {
-      const uint32_t key = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, flags);
-      if (FIRST && edge_w) {
-        const float w = edge_w[e];
-        if (!(fabsf(w) <= 3.402823466e38f)) flags |= FSW_FLAG_W_NONFINITE;
-        if (w < 0.f) flags |= FSW_FLAG_W_NEGATIVE;
+  // half a tile's loads in flight, then its LDS atomics
+  constexpr int kHalf = kRsItems / 2;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t key[kHalf];
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) {
+      const int64_t e = tile0 + (int64_t)(h * kHalf + i) * kRsThreads + threadIdx.x;
+      key[i] = 0xffffffffu;
+      if (e < num_edges) {
+        key[i] = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, flags);
+        if (FIRST && edge_w) {
+          const float w = edge_w[e];
+          if (!(fabsf(w) <= 3.402823466e38f)) flags |= FSW_FLAG_W_NONFINITE;
+          if (w < 0.f) flags |= FSW_FLAG_W_NEGATIVE;
+        }
       }
-      atomicAdd(&hist[(key >> shift) & mask], 1);
     }
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i)
+      if (tile0 + (int64_t)(h * kHalf + i) * kRsThreads + threadIdx.x < num_edges) atomicAdd(&hist[(key[i] >> shift) & mask], 1);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < ndigits; d += kRsThreads) counts[(int64_t)d * ntiles + blockIdx.x] = hist[d];
@@ -195,46 +224,47 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_downsweep(const int64_t* __re
   VAL val[kRsItems];
   int rank[kRsItems];
   int dummy = 0;
+  // two half-tiles of 8 rounds: all loads of a half are issued before its first match (the matches are ~60 vector
+  // instructions a round; with the loads inside the rounds every round waited for its own HBM access)
+  constexpr int kHalf = kRsItems / 2;
 #pragma unroll
-  for (int i = 0; i < kRsItems; ++i) {
-    const int64_t e = wave0 + (int64_t)i * kWave + lane;
-    const bool ok = e < num_edges;
-    key[i] = 0xffffffffu;
-    val[i] = VAL(0);
-    if (ok) {
-      key[i] = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, dummy);
-      if constexpr (FIRST && EID) {
-        val[i] = (VAL)(uint32_t)e;
-      } else if constexpr (FIRST) {
-        const uint32_t s = (uint32_t)senders[e];
-        if constexpr (sizeof(VAL) == 8)
-          val[i] = (VAL)s | ((VAL)__float_as_uint(edge_w[e]) << 32);
-        else
-          val[i] = (VAL)s;
-      } else {
-        val[i] = vals_in[e];
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = h * kHalf; i < (h + 1) * kHalf; ++i) {
+      const int64_t e = wave0 + (int64_t)i * kWave + lane;
+      const bool ok = e < num_edges;
+      key[i] = 0xffffffffu;
+      val[i] = VAL(0);
+      if (ok) {
+        key[i] = load_key<FIRST>(recipients, senders, keys_in, e, num_rows, num_cols, dummy);
+        if constexpr (FIRST && EID) {
+          val[i] = (VAL)(uint32_t)e;
+        } else if constexpr (FIRST) {
+          const uint32_t s = (uint32_t)senders[e];
+          if constexpr (sizeof(VAL) == 8)
+            val[i] = (VAL)s | ((VAL)__float_as_uint(edge_w[e]) << 32);
+          else
+            val[i] = (VAL)s;
+        } else {
+          val[i] = vals_in[e];
+        }
       }
     }
-    // match: lanes of this round with the same digit (inactive tail lanes form their own group, never stored)
-    const uint32_t d = ok ? ((key[i] >> shift) & mask) : (uint32_t)ndigits;
-    unsigned long long peers = __ballot(ok) ;
-    if (!ok) peers = ~peers;
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      if (b < nbits) {
-        const unsigned long long bb = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? bb : ~bb;
+    for (int i = h * kHalf; i < (h + 1) * kHalf; ++i) {
+      const bool ok = wave0 + (int64_t)i * kWave + lane < num_edges;
+      const uint32_t d = (key[i] >> shift) & mask;
+      const unsigned long long peers = match_digit<9>(d, ok);
+      const int leader = __ffsll((long long)peers) - 1;
+      const int below = __popcll(peers & ((1ull << lane) - 1ull));
+      int prev = 0;
+      if (ok && lane == leader) {
+        prev = wcnt[wv][d];
+        wcnt[wv][d] = prev + __popcll(peers);
       }
+      prev = __shfl(prev, leader);
+      rank[i] = prev + below;
     }
-    const int leader = __ffsll((long long)peers) - 1;
-    const int below = __popcll(peers & ((1ull << lane) - 1ull));
-    int prev = 0;
-    if (ok && lane == leader) {
-      prev = wcnt[wv][d];
-      wcnt[wv][d] = prev + __popcll(peers);
-    }
-    prev = __shfl(prev, leader);
-    rank[i] = prev + below;
   }
   __syncthreads();
   // per digit: exclusive bases across waves and the tile-local digit start
@@ -644,12 +674,13 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
                                                                       const int32_t* __restrict__ bstart, int64_t bstride, int ntable,
                                                                       int64_t num_edges, int64_t num_rows, int rb,
                                                                       int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                                                      float* __restrict__ w) {
-  extern __shared__ int bsm[];   // wcnt[kBucketWaves][R] | tot[R]
+                                                                      float* __restrict__ w, int stage_cap) {
+  extern __shared__ int bsm[];   // wcnt[kBucketWaves][R] | tot[R] | stage[stage_cap] values (VAL)
   const int R = 1 << rb;
   const uint32_t rmask = (uint32_t)R - 1u;
   int* wcnt = bsm;
   int* tot = bsm + kBucketWaves * R;
+  VAL* stage = reinterpret_cast<VAL*>(bsm + (kBucketWaves + 1) * R);
   __shared__ int wsum[kBucketWaves];
   const int b = blockIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
   const int64_t s = bstart[(int64_t)b * bstride];
@@ -660,6 +691,9 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
   const int64_t L = ceil_div(e - s, (int64_t)kBucketWaves * kWave) * kWave;
   const int64_t w0 = min(s + wv * L, e), w1 = min(w0 + L, e);
   int* mine = wcnt + wv * R;
+  // a bucket that fits the staging tile is put in order in LDS and leaves as whole lines; a larger one scatters its 4-byte
+  // stores over its window of col[] (8x the write traffic when 500 buckets' windows compete for the L2s: PMC WRITE_SIZE)
+  const bool staged = e - s <= stage_cap;
   for (int64_t i = w0 + lane; i < w1; i += kBucketAhead * kWave) {   // kBucketAhead loads in flight, then the LDS atomics
     uint32_t kk[kBucketAhead];
 #pragma unroll
@@ -723,15 +757,7 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
       const bool ok = g0 + u * kWave + lane < w1;
       const uint32_t key = keyv[u];
       const uint32_t k = key & rmask;
-      unsigned long long peers = __ballot(ok);
-      if (!ok) peers = ~peers;
-#pragma unroll
-      for (int q = 0; q < kBucketMaxRowBits; ++q) {
-        if (q < rb) {
-          const unsigned long long bb = __ballot((k >> q) & 1u);
-          peers &= ((k >> q) & 1u) ? bb : ~bb;
-        }
-      }
+      const unsigned long long peers = match_digit<kBucketMaxRowBits>(k, ok);
       const int leader = __ffsll((long long)peers) - 1;
       const int below = __popcll(peers & ((1ull << lane) - 1ull));
       int prev = 0;
@@ -741,10 +767,25 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
       }
       prev = __shfl(prev, leader);
       if (ok && (int64_t)key < num_rows) {
-        const int64_t pos = s + tot[k] + prev + below;
-        col[pos] = (int32_t)(uint32_t)valv[u];
-        if constexpr (sizeof(VAL) == 8) w[pos] = __uint_as_float((uint32_t)(valv[u] >> 32));
+        const int lpos = tot[k] + prev + below;
+        if (staged) {
+          stage[lpos] = valv[u];
+        } else {
+          col[s + lpos] = (int32_t)(uint32_t)valv[u];
+          if constexpr (sizeof(VAL) == 8) w[s + lpos] = __uint_as_float((uint32_t)(valv[u] >> 32));
+        }
       }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    // valid entries of the bucket: everything below the run of the sentinel row (invalid edges), if that row lives here
+    const int64_t sent = num_rows - (int64_t)b * R;
+    const int nvalid = (sent >= 0 && sent < R) ? tot[sent] : (int)(e - s);
+    for (int i = threadIdx.x; i < nvalid; i += blockDim.x) {
+      const VAL v = stage[i];
+      col[s + i] = (int32_t)(uint32_t)v;
+      if constexpr (sizeof(VAL) == 8) w[s + i] = __uint_as_float((uint32_t)(v >> 32));
     }
   }
 }
@@ -788,18 +829,25 @@ static int sort_and_finish_two_level(const int64_t* recipients, const int64_t* s
     bstride = 1;
     ntable = (int)nbuckets + 1;
   }
-  const size_t lds = sizeof(int) * (size_t)(kBucketWaves + 1) * ((size_t)1 << rb);
+  // LDS: the tables, and -- when the average bucket (+ 3 %) fits what is left of 160 KB -- a staging tile for the bucket's values
+  // (one workgroup per CU then); without it two workgroups share a CU
+  const size_t tables = sizeof(int) * (size_t)(kBucketWaves + 1) * ((size_t)1 << rb);
+  const size_t room = (size_t)160 * 1024 - 1024 - tables;                      // 1 KB for the static arrays
+  const int64_t avg = ceil_div(num_edges, nbuckets);
+  const int64_t want = avg + avg / 32 + 256;   // random graphs: max bucket ~ avg + 4 sqrt(avg); a larger bucket scatters
+  const int stage_cap = (want * (int64_t)sizeof(VAL) <= (int64_t)room) ? (int)(room / sizeof(VAL)) : 0;
+  const size_t lds = tables + (size_t)stage_cap * sizeof(VAL);
   static bool attr_set = false;
   if (!attr_set) {
     FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(sizeof(int) * (kBucketWaves + 1) * (1 << kBucketMaxRowBits))));
+                                      160 * 1024 - 1024));
     FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<unsigned long long>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(sizeof(int) * (kBucketWaves + 1) * (1 << kBucketMaxRowBits))));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     attr_set = true;
   }
   k_bucket_rows<VAL><<<(unsigned)nbuckets, kBucketWaves * kWave, lds, stream>>>(g.keys[cur], reinterpret_cast<const VAL*>(g.vals[cur]), bstart,
-                                                                              bstride, ntable, num_edges, num_rows, rb, rowptr, col, w);
+                                                                              bstride, ntable, num_edges, num_rows, rb, rowptr, col, w,
+                                                                              stage_cap);
   FSW_LAUNCH_CHECK();
   return 0;
 }
