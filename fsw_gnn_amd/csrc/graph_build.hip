@@ -23,8 +23,11 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 16;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-constexpr int kRsThreads = 256;
-constexpr int kRsItems = 16;                      // rounds of 64 consecutive edges per wave
+#ifndef FSW_RS_THREADS
+#define FSW_RS_THREADS 512   // 8 wavefronts x 8 rounds per 4096-edge tile (256 x 16: 0.273 -> 0.253 ms for the build at config 3)
+#endif
+constexpr int kRsThreads = FSW_RS_THREADS;
+constexpr int kRsItems = 4096 / kRsThreads;                      // rounds of 64 consecutive edges per wave
 constexpr int kRsTile = kRsThreads * kRsItems;    // 4096 edges per tile
 constexpr int kRsWaves = kRsThreads / kWave;
 constexpr int kRsMaxDigits = 512;                 // 9 bits: the bucket pass of the two-level build (below)
@@ -694,13 +697,23 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
   // a bucket that fits the staging tile is put in order in LDS and leaves as whole lines; a larger one scatters its 4-byte
   // stores over its window of col[] (8x the write traffic when 500 buckets' windows compete for the L2s: PMC WRITE_SIZE)
   const bool staged = e - s <= stage_cap;
-  for (int64_t i = w0 + lane; i < w1; i += kBucketAhead * kWave) {   // kBucketAhead loads in flight, then the LDS atomics
-    uint32_t kk[kBucketAhead];
+  {  // kBucketAhead loads in flight (the next group's issued before this group's LDS atomics)
+    uint32_t kn[kBucketAhead];
 #pragma unroll
-    for (int u = 0; u < kBucketAhead; ++u) kk[u] = i + u * kWave < w1 ? keys[i + u * kWave] : 0u;
+    for (int u = 0; u < kBucketAhead; ++u) kn[u] = w0 + lane + u * kWave < w1 ? keys[w0 + lane + u * kWave] : 0u;
+    for (int64_t i = w0 + lane; i < w1; i += kBucketAhead * kWave) {
+      uint32_t kk[kBucketAhead];
 #pragma unroll
-    for (int u = 0; u < kBucketAhead; ++u)
-      if (i + u * kWave < w1) atomicAdd(&mine[kk[u] & rmask], 1);
+      for (int u = 0; u < kBucketAhead; ++u) kk[u] = kn[u];
+      const int64_t nx = i + kBucketAhead * kWave;
+      if (nx - lane < w1) {
+#pragma unroll
+        for (int u = 0; u < kBucketAhead; ++u) kn[u] = nx + u * kWave < w1 ? keys[nx + u * kWave] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kBucketAhead; ++u)
+        if (i + u * kWave < w1) atomicAdd(&mine[kk[u] & rmask], 1);
+    }
   }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
@@ -742,15 +755,28 @@ __global__ void __launch_bounds__(kBucketWaves * kWave) k_bucket_rows(const uint
       }
   }
   __syncthreads();
+  // the next group's loads are issued before the current group is ranked (two wavefronts per SIMD do not hide an HBM round
+  // trip per group on their own)
+  uint32_t keyn[kBucketAhead];
+  VAL valn[kBucketAhead];
+  auto load_group = [&](int64_t g) {
+#pragma unroll
+    for (int u = 0; u < kBucketAhead; ++u) {
+      const int64_t i = g + u * kWave + lane;
+      keyn[u] = i < w1 ? keys[i] : 0xffffffffu;
+      valn[u] = i < w1 ? vals[i] : VAL(0);
+    }
+  };
+  load_group(w0);
   for (int64_t g0 = w0; g0 < w1; g0 += kBucketAhead * kWave) {
     uint32_t keyv[kBucketAhead];
     VAL valv[kBucketAhead];
 #pragma unroll
     for (int u = 0; u < kBucketAhead; ++u) {
-      const int64_t i = g0 + u * kWave + lane;
-      keyv[u] = i < w1 ? keys[i] : 0xffffffffu;
-      valv[u] = i < w1 ? vals[i] : VAL(0);
+      keyv[u] = keyn[u];
+      valv[u] = valn[u];
     }
+    if (g0 + kBucketAhead * kWave < w1) load_group(g0 + kBucketAhead * kWave);
 #pragma unroll
     for (int u = 0; u < kBucketAhead; ++u) {
       if (g0 + u * kWave >= w1) break;                       // wave-uniform
