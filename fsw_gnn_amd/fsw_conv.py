@@ -281,6 +281,13 @@ class FSW_conv(_Base):
                 return y
             self._saw_long_rows = True
 
+        if self._split_first_linear():
+            emb = torch.empty((n, E), dtype=x.dtype, device=x.device)
+            emb_mod.embed_into(x, graph, emb, out_scale=scale, prepared=prepared)
+            if prepared is None and self._fusable():
+                st = graph.stats()
+                self._saw_long_rows = st[_lib.STAT_NUM_LDS] > 0 or st[_lib.STAT_NUM_GLOBAL] > 0
+            return self._tail_split(emb, x)
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
         xc = buf[:, E:] if self.concat_self else None   # right half of cat((emb, x))
@@ -327,6 +334,24 @@ class FSW_conv(_Base):
         h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
         out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
         return self.bn_final(out) if self.bn_final is not None else out
+
+    def _split_first_linear(self):
+        """Inference tail without the concat buffer: possible when the first module after cat((emb, x)) is a Linear layer."""
+        return (self.concat_self and self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear)
+                and self.mlp[0].in_features == self.embed_dim + self.in_channels)
+
+    def _tail_split(self, emb, x):
+        """Linear(cat((emb, x))) = emb . W1^T + x . W2^T + b: two GEMMs on the embedding and on x where they lie (no
+        [n, embed_dim + in_channels] buffer -- 4 GB written and read again at 4M nodes x 256 features), then the rest of the tail
+        (reference fsw_conv.py:357-369)."""
+        E = self.embed_dim
+        lin = self.mlp[0]
+        W = lin.weight.detach()
+        y = torch.addmm(lin.bias.detach(), emb, W[:, :E].t()) if lin.bias is not None else emb @ W[:, :E].t()
+        y.addmm_(x, W[:, E:].t())
+        for m in self.mlp[1:]:
+            y = m(y)
+        return self.bn_final(y) if self.bn_final is not None else y
 
     def _tail_buffer(self, buf):
         """The same tail on the concat buffer the kernels filled in place (inference)."""
@@ -389,6 +414,12 @@ class FSW_conv(_Base):
             raise NotImplementedError("fsw_gnn_amd: the sharded-consumer form needs the fused configuration (csrc/conv_fused.hip)")
         if sp['output'] == 'sharded':
             raise NotImplementedError("fsw_gnn_amd: output='sharded' exists for the sharded-consumer form only")
+        if self._split_first_linear():      # the same tail as on one GPU, so the gathered layer stays bit-identical to it
+            emb = torch.empty((n, E), dtype=x.dtype, device=x.device)
+            D.sharded_embed_into(emb_mod, x, graph, emb, out_scale=scale, group=group, x_copy=None, prepared=prepared, stats=stats)
+            if stats is not None:
+                stats["mode"] = "gather"
+            return self._tail_split(emb, x)
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
         xc = buf[:, E:] if self.concat_self else None
