@@ -519,6 +519,10 @@ class FSW_conv(_Base):
             mine = torch.nonzero((rel >= 0) & (rel < nl)).squeeze(1)                        # one compaction for both endpoints
             sub = edge_index.index_select(1, mine)
             graph = build_csr(sub[1] - r0, sub[0], None, nl, n, want_invperm=True)          # nl recipient rows, n sender columns
+            # recipients outside [0, n) belong to no rank's block: flag them like the CSR build flags a bad endpoint (read with
+            # the stats in prepare(): "adjacency index out of range", as on one GPU)
+            oob = ((edge_index[1] < 0) | (edge_index[1] >= n)).any().to(torch.int32) * _lib.FLAG_INDEX_RANGE
+            graph.stats_dev[_lib.STAT_FLAGS:_lib.STAT_FLAGS + 1].bitwise_or_(oob.reshape(1))
             wq, w2 = self._fused_weight()
             prepared = emb.prepare(x, graph)                    # Xp of ALL senders: replicated work, no communication
             st = prepared["stats"]
