@@ -18,6 +18,7 @@ MID_SIZES = (40, 48, 64, 80, 96, 128, 160, 192, 256)   # FSW_MID_SIZES: padded r
 NUM_LDS_BINS = 3                                          # FSW_NUM_LDS_BINS: degrees <= 512, 1024, 2048
 NUM_HUB_BINS = 4                                          # FSW_NUM_HUB_BINS: degrees <= 4096, 8192, 16384, 32768
 HUB_MAX_DEG = 32768
+BIN_MID0 = REG_MAX_DEG + 1      # first bin above the register path (include/fsw_hip.h: FSW_BIN_MID0)
 NUM_BINS = REG_MAX_DEG + 1 + len(MID_SIZES) + NUM_LDS_BINS + NUM_HUB_BINS + 1
 NUM_STATS = 8
 STAT_FLAGS, STAT_MAX_DEGREE, STAT_NUM_ZERO, STAT_NUM_REG, STAT_NUM_LDS, STAT_NUM_GLOBAL, STAT_NNZ, STAT_USER = 0, 1, 2, 3, 4, 5, 6, 7

@@ -337,8 +337,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   const fsw_embed_args& e = *args;
   FSW_REQUIRE(e.rowptr && e.col && e.perm && e.bin_start && e.Xp && e.unit_table, "fsw_conv_fused_f32: null pointer in args");
   FSW_REQUIRE(e.w == nullptr && e.tau <= 1.f, "fsw_conv_fused_f32: unit weights with tau <= 1 only");
-  FSW_REQUIRE(e.num_lds_rows == 0 && e.num_global_rows == 0,
-              "fsw_conv_fused_f32: rows with in-degree > %d must take the unfused path", FSW_REG_MAX_DEG);
+  // rows above FSW_REG_MAX_DEG are not visited: the caller finishes them with fsw_embed_f32 + its own GEMM (fsw_conv.py)
   FSW_REQUIRE(e.S >= 1 && e.ldp >= e.S && e.ldt >= e.S && (e.has_mass == 0 || e.has_mass == 1), "fsw_conv_fused_f32: bad sizes");
   FSW_REQUIRE(!Yin || ldyin >= Hout, "fsw_conv_fused_f32: bad Yin stride");
   FSW_REQUIRE(Hout >= 1 && ldy >= Hout && ldw >= ((Hout + 31) / 32) * 32 && ldw % 32 == 0, "fsw_conv_fused_f32: bad output sizes");

@@ -261,32 +261,36 @@ class FSW_conv(_Base):
             return self._tail(emb, vertex_features)
 
         prepared = None
-        # The fused kernel needs every row within the register path, which only the stats read inside prepare() tells.  The
-        # projection is launched before that read (so the host round trip hides under it) on the assumption that this graph
-        # looks like the previous one: after a graph with long rows the x . W2^T block is not computed speculatively.
-        if self._fusable() and not getattr(self, '_saw_long_rows', False):
+        # The fused kernel covers the rows of at most REG_MAX_DEG neighbours; the stats read inside prepare() tells whether the
+        # graph has longer ones, which are then finished by the long-row kernels + one GEMM on those rows (_finish_long_rows).
+        if self._fusable():
             # fast path: the projection GEMM also produces x . W2^T + b, then ONE kernel does the neighbourhood
             # embedding and E . W1^T (+ activation); the embedding never reaches HBM (csrc/conv_fused.hip)
             lin = self.mlp[0]
             wq, w2 = self._fused_weight()
             y = torch.empty((n, lin.out_features), dtype=x.dtype, device=x.device)
             yin = torch.empty_like(y) if self.concat_self else None      # x . W2^T + b in degree-bin row order
-            lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, yin) if self.concat_self else None
+            # up to 128 features the projection kernel produces that block as four more 32-column slabs of the same pass; above,
+            # its slabs take a third pass over X (3.8 ms at 4M x 256), more than a BLAS GEMM + one row permutation (2.9 ms)
+            in_kernel = self.concat_self and self.in_channels <= 128
+            lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, yin) if in_kernel else None
             prepared = emb_mod.prepare(x, graph, linear2=lin2)
+            if self.concat_self and not in_kernel:
+                y2 = torch.addmm(lin.bias.detach(), x, w2.t()) if lin.bias is not None else x @ w2.t()
+                torch.index_select(y2, 0, graph.perm.long(), out=yin)
             st = prepared["stats"]
-            if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
-                next_module = self._fused_linear(graph, prepared, scale, wq, yin, y)
+            if prepared["unit_fast"]:
+                next_module = self._fused_linear(graph, prepared, scale, wq, yin, y)     # every row of at most 32 neighbours
+                nlong = st[_lib.STAT_NUM_LDS] + st[_lib.STAT_NUM_GLOBAL]
+                if nlong > 0:
+                    self._finish_long_rows(x, graph, prepared, scale, yin, y, next_module)
                 for m in self.mlp[next_module:]:
                     y = m(y)
                 return y
-            self._saw_long_rows = True
 
         if self._split_first_linear():
             emb = torch.empty((n, E), dtype=x.dtype, device=x.device)
             emb_mod.embed_into(x, graph, emb, out_scale=scale, prepared=prepared)
-            if prepared is None and self._fusable():
-                st = graph.stats()
-                self._saw_long_rows = st[_lib.STAT_NUM_LDS] > 0 or st[_lib.STAT_NUM_GLOBAL] > 0
             return self._tail_split(emb, x)
         width = E + self.in_channels if self.concat_self else E
         buf = torch.empty((n, width), dtype=x.dtype, device=x.device)
@@ -297,9 +301,6 @@ class FSW_conv(_Base):
                 xc.copy_(x)
         else:
             emb_mod.embed_into(x, graph, buf, out_scale=scale, x_copy=xc)   # X stored by the projection kernel
-            if self._fusable():
-                st = graph.stats()
-                self._saw_long_rows = st[_lib.STAT_NUM_LDS] > 0 or st[_lib.STAT_NUM_GLOBAL] > 0
         return self._tail_buffer(buf)
 
     def adjacency_coo(self, edge_index, edge_features, num_vertices, dtype):
@@ -463,6 +464,28 @@ class FSW_conv(_Base):
                                    _lib.ptr(w2), self.in_channels, torch.cuda.current_stream(W.device).cuda_stream)
         _lib.check(rc, "fsw_pack_linear_f32")
         return wq, w2
+
+    def _finish_long_rows(self, x, graph, prepared, scale, yin, y, next_module):
+        """Rows above REG_MAX_DEG neighbours of a layer that otherwise runs the fused kernel: their embeddings come from the
+        long-row kernels (mid / wave-sort / hub / giant), the first Linear layer for those rows from one GEMM on the gathered
+        rows.  A graph with a few hubs keeps the fused kernel for everything else."""
+        emb_mod = self.fsw_embed
+        lin = self.mlp[0]
+        E = self.embed_dim
+        bsh = graph.bin_start_host[0]
+        p0, p1 = int(bsh[_lib.BIN_MID0]), int(bsh[_lib.NUM_BINS])         # perm positions of the long rows: one contiguous run
+        rows = graph.perm[p0:p1].long()
+        emb = torch.empty((graph.num_rows, E), dtype=x.dtype, device=x.device)   # only the long rows are written (and read)
+        emb_mod.embed_into(x, graph, emb, out_scale=scale, prepared=prepared, long_rows_only=True)
+        el = emb.index_select(0, rows)
+        W1 = lin.weight.detach()[:, :E]
+        if yin is not None:                       # x . W2^T + b of these rows: rows p0..p1-1 of the degree-ordered block
+            yl = torch.addmm(yin[p0:p1], el, W1.t())
+        else:
+            yl = torch.addmm(lin.bias.detach(), el, W1.t()) if lin.bias is not None else el @ W1.t()
+        if next_module == 2:
+            yl = self.mlp[1](yl)
+        y.index_copy_(0, rows, yl)
 
     def _fused_linear(self, graph, prepared, scale, wq, yin, y):
         L = _lib.lib()

@@ -814,7 +814,7 @@ class FSW_embedding(nn.Module):
         return a
 
     def embed_into(self, X, graph: CSRGraph, out, out_scale=1.0, serialize_num_slices=None, slice_range=None, x_copy=None,
-                   prepared=None, chunks=None):
+                   prepared=None, chunks=None, long_rows_only=False):
         """Writes out_scale * E(X, graph) into the left columns of `out` (row stride out.stride(0)).
 
         X [num_cols, d_in] float32 contiguous; out [num_rows, >= width] float32 with unit inner stride, where
@@ -823,6 +823,7 @@ class FSW_embedding(nn.Module):
         x_copy (optional [num_cols, d_in] view with unit inner stride): the projection kernel also stores X there
         (FSW_conv's concat buffer, reference fsw_conv.py:357-358).
         prepared: the result of prepare() (its slice_range is used); chunks: row chunks to process (default all).
+        long_rows_only: write only the rows of more than REG_MAX_DEG neighbours (the other rows of `out` are not touched).
         This is the hot path: projection (MFMA) -> coefficient table -> fused neighbourhood kernels.
         """
         L = _lib.lib()
@@ -895,6 +896,8 @@ class FSW_embedding(nn.Module):
                 a = self.make_args(graph, st, Xp, ldp, fc, Sc, table, out.data_ptr() + 4 * col0, out.stride(0),
                                    (bias.data_ptr() + 4 * col0) if bias is not None else None, out_scale, hm, scratch,
                                    slice_offset=ka + k0, chunk=c)
+                if long_rows_only:      # rows above REG_MAX_DEG only (FSW_conv: the fused kernel did the others)
+                    a.num_reg_rows, a.num_zero_rows = 0, 0
                 rc = L.fsw_embed_f32(ctypes.byref(a), stream)
                 _lib.check(rc, "fsw_embed_f32")
 

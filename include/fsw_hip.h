@@ -215,8 +215,10 @@ int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
  *   fsw_conv_fused_f32      neighbourhood kernel + E . W1^T on the fp32 matrix cores; with Yin != NULL it
  *                           adds row invperm-position p of Yin [n, ldyin] (else lin_bias), applies the
  *                           activation (0 none, 1 relu, 2 leaky relu with `slope`) and stores Y [n, ldy].
- * Preconditions of fsw_conv_fused_f32: unit weights (args->w == NULL), tau <= 1, no row above
- * FSW_REG_MAX_DEG (args->num_lds_rows == num_global_rows == 0), fsw_conv_fused_lds_bytes() <= 64 KiB.
+ * Preconditions of fsw_conv_fused_f32: unit weights (args->w == NULL), tau <= 1, fsw_conv_fused_lds_bytes() <= 64 KiB.
+ * It computes the rows of in-degree 0 .. FSW_REG_MAX_DEG; rows above that are left untouched in Y -- the caller runs
+ * fsw_embed_f32 for them (num_reg_rows = num_zero_rows = 0 restricts that call to the long rows) and applies the Linear
+ * layer to those rows itself (fsw_gnn_amd/fsw_conv.py does: a graph with a few hubs keeps the fused kernel for the rest).
  * args->out / ldo are ignored.  Wq: W1^T packed for 16-byte operand loads, zero padded:
  *   Wq[((g*ldw + j)*8) + 4*h + i] = W1[j][8g + 2i + h],  g < ceil(K/8) + 16 (the tail groups are zero:
  *   the kernel prefetches past the end), j < ldw (Hout rounded up to 32), K = has_mass + S, h in {0,1},

@@ -985,6 +985,38 @@ def test_store_and_sum_backward_matches_atomic_backward_and_is_reproducible(dev)
     assert torch.equal(runs[0], runs[1])
 
 
+@pytest.mark.parametrize("concat_self,act", [(True, "leaky"), (False, "relu")])
+def test_fused_layer_with_a_few_long_rows_matches_unfused(dev, concat_self, act):
+    """A graph whose rows mostly fit the fused kernel (<= 32 neighbours) plus rows of 33 .. 40 000 neighbours: the layer keeps
+    the fused kernel for the short rows and finishes the long ones with the long-row kernels + one GEMM on those rows; the
+    result must equal the unfused layer (every row through the embedding kernels + torch Linear), itself pinned to the oracle
+    by the tests above."""
+    from fsw_gnn_amd import FSW_conv
+    rng = np.random.default_rng(5)
+    n = 45_000
+    rec = rng.integers(0, n, size=300_000)
+    snd = rng.integers(0, n, size=300_000)
+    extra_r, extra_s = [], []
+    for row, deg in ((11, 33), (12, 100), (13, 257), (14, 700), (15, 1500), (16, 2049), (17, 9000), (18, 40_000), (n - 1, 64)):
+        extra_r.append(np.full(deg, row))
+        extra_s.append(rng.choice(n, size=deg, replace=False))
+    ei = torch.from_numpy(np.stack([np.concatenate([snd] + extra_s), np.concatenate([rec] + extra_r)])).to(dev)
+    x = torch.from_numpy(rng.standard_normal((n, 24)).astype(np.float32)).to(dev)
+    torch.manual_seed(3)
+    conv = FSW_conv(24, 40, embed_dim=65, concat_self=concat_self, mlp_layers=2, mlp_hidden_dim=56,
+                    mlp_activation_hidden=torch.nn.LeakyReLU(0.2) if act == "leaky" else torch.nn.ReLU(), device=dev)
+    with torch.no_grad():
+        assert conv._fusable()
+        y = conv(x, ei)
+        conv.fuse_linear = False
+        ref = conv(x, ei)
+    assert torch.isfinite(y).all()
+    err = float((y - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    rows = torch.tensor([11, 12, 13, 14, 15, 16, 17, 18, n - 1, 0, 1, 2], device=dev)
+    assert float((y[rows] - ref[rows]).abs().max() / ref[rows].abs().max()) < 1e-5
+
+
 def test_backward_conv10k_training_step(dev):
     gg = golden("grads_conv10k")
     c = cases.conv10k()
@@ -1030,6 +1062,7 @@ def test_backward_conv10k_training_step(dev):
     (700, 5000, 16, 8, 33, {"concat_self": False}),                 # no vertex-feature block
     (900, 8000, 12, 24, 70, {"encode_vertex_degrees": False, "mlp_activation_final": torch.nn.ReLU()}),
     (600, 5000, 8, 300, 41, {"vertex_degree_encoding_function": "log", "message_weight_vs_self": 0.5}),   # > 256 outputs
+    (600, 5000, 160, 32, 65, {}),                                   # > 128 features: x . W2^T by BLAS + row permutation
 ])
 def test_fused_conv_odd_shapes_match_unfused_and_oracle(dev, n, E, d, out_ch, embed_dim, kw):
     """The fused Linear kernel, the unfused kernels and the oracle agree on shapes off the aligned fast paths."""
