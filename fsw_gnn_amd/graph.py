@@ -60,7 +60,9 @@ class CSRGraph:
             self.bin_start_host = host[_lib.NUM_STATS:].reshape(self.num_chunks, _lib.NUM_BINS + 1)
         else:
             self._stats = self.stats_dev.cpu().tolist()
-        if self._stats[_lib.STAT_MAX_DEGREE] > TWO_LEVEL_MAX_DEGREE:
+        global _last_graph_skewed
+        _last_graph_skewed = self._stats[_lib.STAT_MAX_DEGREE] > TWO_LEVEL_MAX_DEGREE
+        if _last_graph_skewed:
             _skewed_shapes.add((self.num_rows, self.num_edges))
         return self._stats
 
@@ -96,6 +98,7 @@ def round_chunk_rows(rows, multiple_of=1):
 # Shapes (rows, edges) whose last build showed hub rows: the two-level build (one workgroup per bucket of 2048 rows) would
 # serialise on the hubs' buckets, so those shapes go back to the LSD passes.  Both builds give the same CSR, entry for entry.
 _skewed_shapes = set()
+_last_graph_skewed = False          # a stream of different graphs (mini-batches of one dataset) usually shares its character
 TWO_LEVEL_MAX_DEGREE = 2048
 
 
@@ -103,7 +106,7 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights).
     chunk_rows > 0: degree bins per chunk of chunk_rows consecutive rows (include/fsw_hip.h, fsw_graph_build).
     algo: 'lsd' (fsw_graph_build), 'two_level' (fsw_graph_build_two_level), or 'auto' = two_level unless the last graph of this
-    shape had a row above TWO_LEVEL_MAX_DEGREE neighbours (noted when its stats are read)."""
+    shape -- or the graph before this one -- had a row above TWO_LEVEL_MAX_DEGREE neighbours (noted when the stats are read)."""
     L = _lib.lib()
     dev = recipients.device
     if dev.type != "cuda":
@@ -129,7 +132,7 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     assert algo in ("auto", "lsd", "two_level")
-    two_level = algo == "two_level" or (algo == "auto" and (num_rows, E) not in _skewed_shapes)
+    two_level = algo == "two_level" or (algo == "auto" and (num_rows, E) not in _skewed_shapes and not _last_graph_skewed)
     fn = L.fsw_graph_build_two_level if two_level else L.fsw_graph_build
     rc = fn(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols, chunk_rows,
             _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
