@@ -24,7 +24,7 @@
 namespace fsw {
 
 constexpr double kPiH = 3.14159265358979323846;
-constexpr int kHubM = 32;                  // keys per lane
+[[maybe_unused]] constexpr int kHubM = 32;                  // keys per lane
 #ifndef FSW_HUB_ABL
 #define FSW_HUB_ABL 0   // timing experiments (tools/exp_hub.sh): 1 no gather, 2 no wave sort, 4 no cross-wave merge
 #endif
@@ -35,6 +35,19 @@ __device__ __forceinline__ float mass_encode_h(float m, int fn) {
   return m;
 }
 
+__device__ __forceinline__ float wave_sum_h(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// The instantiations are split over three translation units (FSW_HUB_PART = 0: unit weights, 1 / 2: general weights up to 2048 /
+// above; see the Makefile): the (key, weight) networks take minutes to compile.
+#ifndef FSW_HUB_PART
+#error "compile with -DFSW_HUB_PART=0|1|2"
+#endif
+
+#if FSW_HUB_PART == 0
 // ---- building blocks shared by the kernels below ---------------------------------------------------------------------
 // register exchange between the wavefronts of a workgroup through xbuf [NW][CAP]: this wavefront keeps, element by
 // element, the smaller (lower) or larger key of (its own, wavefront `partner`'s -- same element, or mirrored)
@@ -104,12 +117,6 @@ __device__ __forceinline__ float unit_readout(const Line& ln, int r0, int D, flo
     c = cn;
   }
   return acc;
-}
-
-__device__ __forceinline__ float wave_sum_h(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
 }
 
 // gather elements t0 + j * 64 + lane (j < M; striped: lane-contiguous col reads -- the chunk is sorted next) of slice k
@@ -421,6 +428,225 @@ static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper,
   return 0;
 }
 
+#endif   // FSW_HUB_PART == 0
+
+// ---- general weights (and tau > 1): the same line-in-registers structure with the weight as payload --------------------------
+// Replaces, for rows of 129 .. 4096 neighbours without edge features, the LDS-staged wave-sort kernels and the scratch-line kernel
+// of embed_wsort.hip (13 .. 43 G keys/s on the 64M-edge RMAT graph).  A line holds D + 1 elements: the neighbours (key, weight)
+// and the reference's pad element (key 0, weight max(tau - m, 0), fsw_embedding.py:1000-1017), so a class runs one size up from
+// the unit kernels.  Readout as in k_embed_wsort: float64 cumulative weight (lane sum -> wave scan -> wavefront offsets), phase
+// reduced in float64, sine in float32, coefficient = difference of consecutive sines.
+__device__ __forceinline__ double wave_exclusive_scan_f64_h(double v, int lane) {
+  double inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const double t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  return inc - v;
+}
+
+__device__ __forceinline__ float sin2pi_rev_h(double x) {
+  const double r = x - rint(x);
+  return sinpif(2.f * (float)r);
+}
+
+template <int M>
+__device__ __forceinline__ void wave_exchange_w(WaveLine<M, true>& ln, float* __restrict__ xk, float* __restrict__ xw, int w, int lane,
+                                                int partner, bool mirrored, bool lower) {
+  constexpr int CAP = M * kWave;
+  float* mk = xk + w * CAP + lane;
+  float* mw = xw + w * CAP + lane;
+  asm volatile("" : "+v"(mk));
+  asm volatile("" : "+v"(mw));
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    mk[j * kWave] = ln.k[j];
+    mw[j * kWave] = ln.w[j];
+  }
+  __syncthreads();
+  const int off = partner * CAP + (mirrored ? kWave - 1 - lane : lane);
+  const float* tk = xk + off;
+  const float* tw = xw + off;
+  asm volatile("" : "+v"(tk));
+  asm volatile("" : "+v"(tw));
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    const int jj = (mirrored ? M - 1 - j : j) * kWave;
+    const float ok = tk[jj], ow = tw[jj];
+    const bool take = lower ? (ok < ln.k[j]) : (ok > ln.k[j]);   // ties: both wavefronts keep their own element
+    ln.k[j] = take ? ok : ln.k[j];
+    ln.w[j] = take ? ow : ln.w[j];
+  }
+  __syncthreads();
+}
+
+template <int NW, int M>
+__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, M >= 24 ? 2 : 3) k_embed_hub_w(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ wgt, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi, const float* __restrict__ Xp, int64_t ldp, int S,
+    const float* __restrict__ freqs, float tau, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
+    int has_mass, int mass_fn, float mass_scale) {
+  constexpr int CAP = M * kWave;
+  constexpr int LPB = NW == 1 ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) float xsm[];   // NW > 1: keys [NW][CAP] | weights [NW][CAP]
+  float* xk = xsm;
+  float* xw = xsm + (NW > 1 ? NW * CAP : 0);
+  __shared__ double redd[NW];
+  __shared__ float red[NW];
+  const int pbeg = bin_start[bin_lo], nrows = bin_start[bin_hi + 1] - pbeg;
+  const int lane = lane_id();
+  const int w = NW == 1 ? 0 : wave_id();
+  const int xcd = blockIdx.x & 7;
+  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
+    const int64_t i = (vb >> 3) * LPB + (NW == 1 ? wave_id() : 0);
+    const int64_t rl = i / S;
+    const int k = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int Dtot = D + 1;                                  // with the pad element; Dtot <= NW * CAP by the class bounds
+
+    // gather (striped: element t0 + j * 64 + lane), total mass, pad element
+    WaveLine<M, true> ln;
+    const int t0 = w * CAP;
+    int c[M];
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int t = t0 + j * kWave + lane;
+      c[j] = t < D ? col[start + t] : -1;
+      ln.w[j] = t < D ? (wgt ? wgt[start + t] : 1.f) : 0.f;
+      part += (double)ln.w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) ln.k[j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    double m = part;
+    if constexpr (NW > 1) {
+      if (lane == 0) redd[w] = part;
+      __syncthreads();
+      m = 0.0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) m += redd[q];
+      __syncthreads();
+    }
+    const double taud = (double)tau;
+    const double inv = 1.0 / fmax(m, taud);
+    {
+      const float padw = (float)fmax(taud - m, 0.0);         // zero weight unless the row is deficient
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if (t0 + j * kWave + lane == D) {
+          ln.k[j] = 0.f;
+          ln.w[j] = padw;
+        }
+    }
+    ln.sort();
+    if constexpr (NW > 1) {
+#pragma unroll
+      for (int size = 2; size <= NW; size <<= 1) {
+        wave_exchange_w<M>(ln, xk, xw, w, lane, w ^ (size - 1), true, (w & (size >> 1)) == 0);
+        for (int st = size >> 2; st >= 1; st >>= 1) wave_exchange_w<M>(ln, xk, xw, w, lane, w ^ st, false, (w & st) == 0);
+        ln.merge_chunk();
+      }
+    }
+    // readout: element (w, lane, j) has rank w * CAP + lane * M + j
+    const float xif = freqs[k];
+    const double xi = (double)xif;
+    const bool lin = xif < 1e-30f;
+    double lsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) lsum += (double)ln.w[j];
+    double cw = wave_exclusive_scan_f64_h(lsum, lane);
+    if constexpr (NW > 1) {
+      const double wtot = __shfl(cw + lsum, kWave - 1);      // this wavefront's total
+      if (lane == 0) redd[w] = wtot;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NW; ++q)
+        if (q < w) cw += redd[q];
+      __syncthreads();
+    }
+    float acc = 0.f;
+    float sprev = lin ? 0.f : sin2pi_rev_h(xi * (cw * inv));
+    const int r0 = w * CAP + lane * M;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const bool valid = r0 + j < Dtot;
+      cw += (double)ln.w[j];
+      if (lin) {
+        acc += valid ? ln.w[j] * ln.k[j] : 0.f;
+      } else {
+        const float sn = sin2pi_rev_h(xi * (cw * inv));
+        acc += valid ? (sn - sprev) * ln.k[j] : 0.f;
+        sprev = sn;
+      }
+    }
+    acc *= lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiH * xi));
+    float tot = wave_sum_h(acc);
+    if constexpr (NW > 1) {
+      if (lane == 0) red[w] = tot;
+      __syncthreads();
+      tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot += red[q];
+      __syncthreads();
+    }
+    if (lane == 0 && w == 0) {
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
+template <int NW, int M>
+static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, hipStream_t stream) {
+  constexpr int LPB = NW == 1 ? 4 : 1;
+  rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
+  if (rows_upper <= 0) return 0;
+  const size_t lds = NW > 1 ? sizeof(float) * 2 * NW * M * kWave : 0;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_hub_w<NW, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
+  const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
+  k_embed_hub_w<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, lds, stream>>>(
+      a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp, a.S, a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale,
+      a.has_mass, a.mass_fn, a.mass_scale);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+#if FSW_HUB_PART == 1
+// general weights without edge features: rows of FSW_MID_MAX_DEG_WEIGHTED < degree <= 4096 (bins bin_lo .. FSW_BIN_HUB0).
+// bin_lo: the first mid bin above FSW_MID_MAX_DEG_WEIGHTED.  lds_rows / hub_rows bound the rows of the two ranges.
+int launch_embed_hub_weighted_lds(const fsw_embed_args& a, int bin_lo, int64_t rows_upper, hipStream_t stream) {
+  // D + 1 elements: a class of up to 2^k neighbours needs 2^k + 1 slots -- 3/4 of the next power of two (6 / 12 / 24 keys per lane)
+  int rc;
+  if (bin_lo < FSW_BIN_LDS0 && (rc = launch_hub_w<1, 6>(a, bin_lo, FSW_BIN_LDS0 - 1, rows_upper, stream))) return rc;    // ..256 (+1) in 384
+  if ((rc = launch_hub_w<1, 12>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, stream))) return rc;                          // ..512 in 768
+  if ((rc = launch_hub_w<1, 24>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;                  // ..1024 in 1536
+  if ((rc = launch_hub_w<2, 24>(a, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, rows_upper, stream))) return rc;                  // ..2048 in 3072
+  return 0;
+}
+#elif FSW_HUB_PART == 2
+int launch_embed_hub_weighted_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  int rc;
+  // ..4096 in 6144.  Above, the scratch-line kernel of embed_wsort.hip stays: sixteen wavefronts x 12 keys (or eight x 24) per
+  // line measured 124 (159) ms on the RMAT graph's class 4097..8192 against its 97 ms -- one workgroup per CU at 96 KB of
+  // exchange buffer does not cover the barrier-separated exchanges
+  if ((rc = launch_hub_w<4, 24>(a, FSW_BIN_HUB0, FSW_BIN_HUB0, rows_upper, stream))) return rc;
+  return 0;
+}
+
+#else
 // unit weights, tau <= 1: rows of the four hub bins.  rows_upper bounds the rows above FSW_LDS_MAX_DEG (the per-bin counts
 // stay on the device: surplus blocks exit at once).
 int launch_embed_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
@@ -447,5 +673,7 @@ int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_
   if ((md <= 0 || md > 1024) && (rc = launch_hub<1, 32>(a, FSW_BIN_LDS0 + 2, rows_upper, stream))) return rc;
   return 0;
 }
+
+#endif
 
 }  // namespace fsw

@@ -418,10 +418,23 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
 }
 
 int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);   // embed_hub.hip
+int launch_embed_hub_weighted_lds(const fsw_embed_args& a, int bin_lo, int64_t rows_upper, hipStream_t stream);
+int launch_embed_hub_weighted_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
+#ifndef FSW_WEIGHTED_HUB
+#define FSW_WEIGHTED_HUB 1   // 0: general weights on the LDS-staged / scratch-line kernels of this file only (for comparison)
+#endif
 
 // general weights: every row above FSW_LDS_MAX_DEG (unit weights with tau <= 1 take embed_hub.hip's kernels)
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
+  // without edge features the rows of up to 4096 neighbours keep their line in registers (embed_hub.hip: k_embed_hub_w)
+  int first_bin = FSW_BIN_HUB0;
+  if (FSW_WEIGHTED_HUB && !a.efeat) {
+    if (int rc = launch_embed_hub_weighted_hub(a, rows_upper, stream)) return rc;
+    first_bin = FSW_BIN_HUB0 + 1;
+    if (a.max_degree > 0 && a.max_degree <= 4096) return 0;
+    if (bin_rows_or(a, first_bin, FSW_BIN_GLOBAL, 1) <= 0) return 0;
+  }
   FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
   FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
   const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
@@ -433,7 +446,7 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
   char* scratch = reinterpret_cast<char*>(a.scratch);
   k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
       a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
-      FSW_BIN_HUB0);
+      first_bin);
   FSW_LAUNCH_CHECK();
   return 0;
 }
@@ -465,6 +478,7 @@ int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
     constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
     int bin_lo = FSW_BIN_MID0;
     while (bin_lo < FSW_BIN_LDS0 && sizes[bin_lo - FSW_BIN_MID0] <= FSW_MID_MAX_DEG_WEIGHTED) ++bin_lo;
+    if (FSW_WEIGHTED_HUB && !a.efeat) return launch_embed_hub_weighted_lds(a, bin_lo, rows_upper, stream);
     if (bin_lo < FSW_BIN_LDS0 && (rc = launch_wsort<8, true>(a, bin_lo, FSW_BIN_LDS0 - 1, rows_upper, stream))) return rc;
     if ((rc = launch_wsort<16, true>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, stream))) return rc;
     if ((rc = launch_wsort<32, true>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;
