@@ -15,8 +15,9 @@ if [ "$1" = build ]; then
     for o in $src/_build/*.o; do
       f=$(basename $o .o)
       case "$f" in
-        embed_reg|conv_fused|project|graph_build|embed_wsort|embed_wsort_bwd|embed_hub) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -c $src/$f.hip -o $o ;;
-        embed_mid|embed_lds) continue ;;   # stale objects of removed / split sources
+        embed_reg|conv_fused|project|graph_build|embed_wsort|embed_wsort_bwd) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -c $src/$f.hip -o $o ;;
+        embed_hub_[0-2]) o=/tmp/var_${name}_$f.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include $flags -DFSW_HUB_PART=${f##*_} -c $src/embed_hub.hip -o $o ;;
+        embed_mid|embed_lds|embed_hub) continue ;;   # stale objects of removed / split sources
       esac
       objs="$objs $o"
     done
