@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
-    int has_mass, int mass_fn, float mass_scale) {
+    int has_mass, int mass_fn, float mass_scale, int dmin, int dmax) {
   constexpr int CAP = M * kWave;
   constexpr int LPB = NW == 1 ? 4 : 1;   // lines per block
   __shared__ float xbuf[NW > 1 ? NW * CAP : 1];   // exchange buffer: element (lane, j) of wavefront w at xbuf[w * CAP + j * 64 + lane]
@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
     const int node = perm[pbeg + r];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
+    if (D < dmin || D > dmax) continue;   // multi-wavefront classes: the 3/4-size instantiation and the full one share a bin
 
     // one wavefront per line: a line of at most 3/4 of the class size runs on 3/4 of the keys per lane (24 / 12 / 6) -- the same
     // network, a quarter fewer comparators; rows spread over (2^k, 2^(k+1)], so about half of them qualify (wave-uniform
@@ -189,8 +190,12 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
     // second code path costs them registers (20..50 spilled), so they always run the full size.
     constexpr int MS = (M * 3) / 4;
     float tot;
-    if (FSW_HUB_SPLIT && NW == 1 && D <= kWave * MS) tot = hub_line<NW, MS>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
-    else tot = hub_line<NW, M>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
+    if constexpr (FSW_HUB_SPLIT && NW == 1) {
+      if (D <= kWave * MS) tot = hub_line<NW, MS>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
+      else tot = hub_line<NW, M>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
+    } else {
+      tot = hub_line<NW, M>(col + start, D, Xp, ldp, k, freqs[k], xbuf, w, lane);
+    }
     if constexpr (NW > 1) {
       if (lane == 0) red[w] = tot;
       __syncthreads();
@@ -352,7 +357,7 @@ int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t 
 }
 
 template <int NW, int M>
-static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
+static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream, int dmin = 0, int dmax = 0x7fffffff) {
   constexpr int LPB = NW == 1 ? 4 : 1;
   rows_upper = bin_rows_or(a, bin, bin, rows_upper);   // exact when the host knows the bins: an empty bin is not launched
   if (rows_upper <= 0) return 0;
@@ -362,9 +367,19 @@ static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipS
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
   k_embed_hub<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, 0, stream>>>(
       a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
-      a.mass_scale);
+      a.mass_scale, dmin, dmax);
   FSW_LAUNCH_CHECK();
   return 0;
+}
+
+// a multi-wavefront class as two launches over its bin: rows of at most 3/4 of the class size on 24 keys per lane, the rest on 32
+// (the single-wavefront classes branch per line inside one kernel; here the second code path would spill)
+template <int NW>
+static int launch_hub_pair(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
+  constexpr int kSmall = NW * kWave * 24;
+  int rc;
+  if (FSW_HUB_SPLIT && (rc = launch_hub<NW, 24>(a, bin, rows_upper, stream, 0, kSmall))) return rc;
+  return launch_hub<NW, kHubM>(a, bin, rows_upper, stream, FSW_HUB_SPLIT ? kSmall + 1 : 0, 0x7fffffff);
 }
 
 
@@ -653,10 +668,10 @@ int launch_embed_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
   if (rows_upper <= 0) return 0;
   int rc;
   const int64_t md = a.max_degree;   // host value, <= 0 when unknown
-  if ((rc = launch_hub<2, kHubM>(a, FSW_BIN_HUB0, rows_upper, stream))) return rc;
-  if ((md <= 0 || md > 4096) && (rc = launch_hub<4, kHubM>(a, FSW_BIN_HUB0 + 1, rows_upper, stream))) return rc;
-  if ((md <= 0 || md > 8192) && (rc = launch_hub<8, kHubM>(a, FSW_BIN_HUB0 + 2, rows_upper, stream))) return rc;
-  if ((md <= 0 || md > 16384) && (rc = launch_hub<16, kHubM>(a, FSW_BIN_HUB0 + 3, rows_upper, stream))) return rc;
+  if ((rc = launch_hub_pair<2>(a, FSW_BIN_HUB0, rows_upper, stream))) return rc;
+  if ((md <= 0 || md > 4096) && (rc = launch_hub_pair<4>(a, FSW_BIN_HUB0 + 1, rows_upper, stream))) return rc;
+  if ((md <= 0 || md > 8192) && (rc = launch_hub_pair<8>(a, FSW_BIN_HUB0 + 2, rows_upper, stream))) return rc;
+  if ((md <= 0 || md > 16384) && (rc = launch_hub_pair<16>(a, FSW_BIN_HUB0 + 3, rows_upper, stream))) return rc;
   return 0;
 }
 
