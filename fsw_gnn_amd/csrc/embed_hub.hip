@@ -146,6 +146,9 @@ __device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, in
   return wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, xif));
 }
 
+#ifndef FSW_ROWLINES_SPLIT
+#define FSW_ROWLINES_SPLIT 0
+#endif
 #ifndef FSW_HUB_ROWLINES
 #define FSW_HUB_ROWLINES 1   // 0: class 257..512 as one 64-lane line of 8 keys per lane (for comparison)
 #endif
@@ -389,14 +392,15 @@ static int launch_hub_pair(const fsw_embed_args& a, int bin, int64_t rows_upper,
 // key instead of two): ~0.8 instead of ~1.2 instructions per key.  The four lines are four adjacent slices of one row, so a
 // gather instruction reads 16 bytes from each of 16 rows of Xp instead of 4 bytes from 64.
 constexpr int kRowLanes = 16;
-constexpr int kRowM = 32;
 
+template <int M>   // 32 keys per lane (512 per line), or 24 for the rows of at most 384 neighbours
 __global__ void __launch_bounds__(256, 4) k_embed_rowlines(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start, int bin,
                                                            const float* __restrict__ Xp, int64_t ldp, int S, const float* __restrict__ freqs,
                                                            float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
-                                                           float out_scale, int has_mass, int mass_fn, float mass_scale) {
-  constexpr int M = kRowM, LPW = kWave / kRowLanes, LPB = 4 * LPW;   // lines per wavefront / per block
+                                                           float out_scale, int has_mass, int mass_fn, float mass_scale, int dmin,
+                                                           int dmax) {
+  constexpr int LPW = kWave / kRowLanes, LPB = 4 * LPW;   // lines per wavefront / per block
   const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
   const int lane = lane_id(), sub = lane & (kRowLanes - 1);
   const int xcd = blockIdx.x & 7;
@@ -409,6 +413,7 @@ __global__ void __launch_bounds__(256, 4) k_embed_rowlines(const int32_t* __rest
     const int node = perm[pbeg + r];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
+    if (D < dmin || D > dmax) continue;   // the 24- and the 32-key instantiation share the bin
     WaveLine<M, false, false, kRowLanes> ln;
     const int32_t* colrow = col + start;
     int c[M];
@@ -437,8 +442,18 @@ static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper,
   if (rows_upper <= 0) return 0;
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
-  k_embed_rowlines<<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo,
-                                                         a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+  // rows of at most 384 neighbours on 24 keys per lane: off by default -- on a graph whose class sits near its upper end (the 64M-edge
+  // RMAT graph: fill 0.93) the extra pass over the bin costs 0.8 ms and finds nothing
+  constexpr int kSmall = kRowLanes * 24;
+  constexpr bool kSplit = FSW_HUB_SPLIT && FSW_ROWLINES_SPLIT;
+  if (kSplit) {
+    k_embed_rowlines<24><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                               a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, 0, kSmall);
+    FSW_LAUNCH_CHECK();
+  }
+  k_embed_rowlines<32><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                             a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
+                                                             kSplit ? kSmall + 1 : 0, 0x7fffffff);
   FSW_LAUNCH_CHECK();
   return 0;
 }
