@@ -11,6 +11,10 @@
 #include "fsw_common.h"
 #include "sortnet.h"
 
+#ifndef FSW_PERMLANE_SWAP
+#define FSW_PERMLANE_SWAP 0   // 1: v_permlane16/32_swap for the half-cleaner distances 16 / 32 -- measured SLOWER than ds_swizzle /
+#endif                        // ds_bpermute on the 64M-edge RMAT graph (hub<4,24> 10.2 -> 11.2 ms, hub<8,32> 7.2 -> 7.3, giant 6.2 -> 6.5)
+
 namespace fsw {
 
 // value of lane ^ MASK.  Distances inside a row of 16 lanes go through DPP (VALU rate, no LDS crossbar): xor 1, 2, 3 are
@@ -50,6 +54,34 @@ struct WaveLine {
   // exchange with another lane: this lane keeps the smaller (lower == true) or the larger key of each pair
   template <int JREV, int MASK>
   __device__ __forceinline__ void exchange(bool lower) {
+#if FSW_PERMLANE_SWAP
+    // distances 16 and 32 of the half-cleaners (lower == ((lane & MASK) == 0)): gfx950's v_permlane16/32_swap puts both members
+    // of a pair into ONE lane for two registers at a time -- swap, v_min + v_max, swap back: two instructions per key like the DPP
+    // path, and no trip through the LDS crossbar (ds_swizzle / ds_bpermute + wait) that these two distances needed
+    if constexpr (!WEIGHTED && JREV == 0 && (MASK == 16 || MASK == 32) && M % 2 == 0) {
+#pragma unroll
+      for (int j = 0; j < M; j += 2) {
+        const unsigned a = __float_as_uint(k[j]), b = __float_as_uint(k[j + 1]);
+        unsigned x, y;
+        if constexpr (MASK == 32) {
+          auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+          x = r[0]; y = r[1];
+        } else {
+          auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+          x = r[0]; y = r[1];
+        }
+        const float mn = fminf(__uint_as_float(x), __uint_as_float(y)), mx = fmaxf(__uint_as_float(x), __uint_as_float(y));
+        if constexpr (MASK == 32) {
+          auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(mn), __float_as_uint(mx), false, false);
+          k[j] = __uint_as_float(q[0]); k[j + 1] = __uint_as_float(q[1]);
+        } else {
+          auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(mn), __float_as_uint(mx), false, false);
+          k[j] = __uint_as_float(q[0]); k[j + 1] = __uint_as_float(q[1]);
+        }
+      }
+      return;
+    }
+#endif
     float ok[M], ow[WEIGHTED ? M : 1];
     const float lim = lower ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
