@@ -146,6 +146,9 @@ __device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, in
   return wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, xif));
 }
 
+#ifndef FSW_HUB_MINWAVES
+#define FSW_HUB_MINWAVES 4   // waves per SIMD the hub kernels are compiled for (128 registers)
+#endif
 #ifndef FSW_ROWLINES_SPLIT
 #define FSW_ROWLINES_SPLIT 0
 #endif
@@ -159,7 +162,7 @@ __device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, in
 // NW wavefronts per line, M keys per lane; NW == 1: the workgroup is four independent wavefronts on four lines (adjacent
 // slices of one row) and never synchronises -- the wave-sort classes 257..2048 (M = 8 / 16 / 32) run this way
 template <int NW, int M>
-__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, 4) k_embed_hub(
+__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, FSW_HUB_MINWAVES) k_embed_hub(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
