@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: edges*slices/sec of FSW_conv.forward on the BASELINE config-3 workload.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 without WORLD_SIZE in the environment: bench.py starts its own ranks -- a CHILD process
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same args>`
+        (one rank per GPU over RCCL), before anything in this process touches the GPU -- relays rank 0's JSON line as the last
+        stdout line and exits with the child's code.  Launched by an outer torch.distributed.run it runs as a rank as before.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): ER-style directed multigraph with
 1,000,000 nodes / 10,000,000 edges, 128 features, FSW_conv(128 -> 128, embed_dim = 257) = 256 slices + degree
@@ -27,6 +31,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,32 +44,89 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_NODES, N_EDGES, D_FEAT, EMBED_DIM, OUT_CH = 1_000_000, 10_000_000, 128, 257, 128
+N_NODES, N_EDGES, D_FEAT, N_SLICES, OUT_CH = 1_000_000, 10_000_000, 128, 256, 128
+EMBED_DIM = N_SLICES + 1            # + the degree column (FSW_conv: encode_vertex_degrees)
+WEAK_SLICES_PER_GPU = 128           # BASELINE config 4: 1024 slices sharded 128 per GPU across 8
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--edges", type=int, default=N_EDGES)
+    ap.add_argument("--slices", type=int, default=N_SLICES,
+                    help="slices of the layer (embed_dim = slices + 1).  256 = BASELINE config 3 (the metric's configuration); "
+                         "1024 = config 4 (128 slices per GPU at 8 GPUs)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-segcumsum", action="store_true", help="skip the stand-alone segmented-cumsum throughput leg")
+    ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling leg (128 slices per GPU, BASELINE config 4's shape)")
     ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
     ap.add_argument("--shard", choices=("slices", "nodes"), default="slices",
                     help="N > 1: 'slices' = BASELINE north_star's slice-axis shard (default); 'nodes' = every rank runs the fused "
                          "layer on its block of recipient rows, all-gather of the 128-wide output (extra, not the contracted partition)")
-    ap.add_argument("--mode", choices=("auto", "consumer", "gather"), default="auto",
-                    help="slice shard: 'consumer' = sharded first Linear layer + reduce-scatter (auto picks it), 'gather' = all-gather of the embedding")
+    ap.add_argument("--forms", default="gather,consumer",
+                    help="N > 1, slice shard: comma-separated forms to time, each over the same K steps: 'gather' = north_star's "
+                         "all-gather of the embedding, 'consumer' = sharded first Linear layer + reduce-scatter + all-gather of the "
+                         "output rows, 'consumer_sharded' = consumer stopping after the reduce-scatter (rows stay with their owner). "
+                         "The headline value is the fastest form that returns the full output on every rank.")
+    ap.add_argument("--mode", choices=("auto", "consumer", "gather"), default=None,
+                    help="(older spelling) time ONE form: consumer / gather; auto = consumer")
     ap.add_argument("--chunks", type=int, default=0, help="node-range chunks of the multi-GPU pipeline (0 = by size)")
     ap.add_argument("--output", choices=("replicated", "sharded"), default="replicated",
-                    help="consumer form: 'sharded' stops after the reduce-scatter (every rank keeps its finished rows)")
-    return ap.parse_args()
+                    help="with --mode consumer: 'sharded' stops after the reduce-scatter (every rank keeps its finished rows)")
+    args = ap.parse_args(argv)
+    if args.mode is not None:
+        args.forms = "gather" if args.mode == "gather" else ("consumer_sharded" if args.output == "sharded" else "consumer")
+    if args.no_fuse:
+        args.forms = "gather"
+    args.forms = [f for f in args.forms.split(",") if f]
+    for f in args.forms:
+        if f not in ("gather", "consumer", "consumer_sharded"):
+            ap.error("unknown form %r" % f)
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(argv, gpus, port, script=None, python=None):
+    """The child command that runs this script as `gpus` ranks of one node (one rank per GPU, RCCL): exactly the line the
+    driver uses for N > 1.  argv = this process's arguments, passed through unchanged."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv, script=None):
+    """Parent of a self-launched N > 1 run.  Nothing here initialises the GPU (no torch.cuda call): the ranks are children.
+    Rank 0's JSON line is relayed as the LAST stdout line, everything else the children print goes to stderr."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launch_command(argv, args.gpus, free_port(), script=script)
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
 
 
 def make_inputs(n, num_edges, dev):
@@ -204,21 +267,27 @@ def collectives_alone(stats, n, H, width, world, reps, dev):
     if not stats:
         return None
     from fsw_gnn_amd import dist as D
-    if stats.get("mode") == "consumer":
-        rows = -(-n // world) * world
-        P = torch.zeros((rows, H), dtype=torch.float32, device=dev)
-        R = torch.empty((rows // world, H), dtype=torch.float32, device=dev)
+    fn, err = None, None
+    try:          # allocation is the part that can fail on one rank alone
+        if stats.get("mode") == "consumer":
+            rows = -(-n // world) * world
+            P = torch.zeros((rows, H), dtype=torch.float32, device=dev)
+            R = torch.empty((rows // world, H), dtype=torch.float32, device=dev)
 
-        def fn():
-            D._reduce_scatter(R, P, None, False)
-            if "all_gather" in stats.get("collective", ""):
-                D._all_gather(P, R, None, False)
-    else:
-        loc = torch.zeros((n, width), dtype=torch.float32, device=dev)
-        flat = torch.empty((world * n, width), dtype=torch.float32, device=dev)
+            def fn():
+                D._reduce_scatter(R, P, None, False)
+                if "all_gather" in stats.get("collective", ""):
+                    D._all_gather(P, R, None, False)
+        else:
+            loc = torch.zeros((n, width), dtype=torch.float32, device=dev)
+            flat = torch.empty((world * n, width), dtype=torch.float32, device=dev)
 
-        def fn():
-            D._all_gather(flat, loc, None, False)
+            def fn():
+                D._all_gather(flat, loc, None, False)
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_ok(err is None, dev, world):
+        return {"collective_error": err or "another rank could not allocate the buffers"}
     ms = timed_ms(fn, reps, dev)
     t = torch.tensor([ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,57 +372,17 @@ def cpu_baseline(x, ei, conv, n, nslices, max_threads):
     return res
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
-    if world > 1:
-        # RCCL ("nccl") over xGMI, one rank per GPU.  FSW_BENCH_BACKEND=gloo is a functional rehearsal on a box with
-        # fewer GPUs than ranks (ranks then share a device; numbers from it mean nothing).
-        backend = os.environ.get("FSW_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from fsw_gnn_amd import FSW_conv
-    n, E = args.nodes, args.edges
-    x, ei = make_inputs(n, E, dev)
-    torch.manual_seed(4321)
-    conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=EMBED_DIM, device=dev)
-    if args.no_fuse:
-        conv.fuse_linear = False
-    sp_stats = {}
-    if world > 1:
-        if args.shard == "nodes" and not args.no_fuse:
-            conv.enable_node_parallel(None)
-        else:
-            conv.enable_slice_parallel(None, mode="gather" if args.no_fuse else args.mode, chunks=args.chunks or None,
-                                       output=args.output, stats=sp_stats)
-    S = conv.fsw_embed.nSlices
-    keys = ei[1] * n + ei[0]
-    e_coalesced = int(torch.unique(keys).numel())          # E' of SURVEY 8(d): edges after the reference's coalesce()
-    del keys
-
-    def step():
-        with torch.no_grad():
-            return conv(x, ei)
-
-    for _ in range(args.warmup):
-        step()
+def timed_steps(step, warmup, steps, dev, world):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; seconds, MAX over ranks."""
+    y = None
+    for _ in range(warmup):
+        y = step()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         y = step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -364,31 +393,218 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
-    assert torch.isfinite(y[0] if isinstance(y, tuple) else y).all()
+    return elapsed, y
+
+
+def all_ranks_ok(ok, dev, world):
+    """True only if EVERY rank passes ok = True: called before a leg that contains collectives, so that a rank which failed
+    while preparing it (out of memory, ...) makes all ranks skip the leg instead of leaving the others blocked in RCCL."""
+    if world == 1:
+        return bool(ok)
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t) == 0
+
+
+FORM_ARGS = {"gather": ("gather", "replicated"), "consumer": ("consumer", "replicated"), "consumer_sharded": ("consumer", "sharded")}
+
+
+def world_record(dev, world, rank, local_rank):
+    """What the process group really is: proves in the record that RCCL saw N ranks, each on its own device."""
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device_name": torch.cuda.get_device_name(dev),
+          "pid": os.getpid(), "host": socket.gethostname()}
+    if world == 1:
+        return {"world_size": 1, "backend": None, "ranks": [me]}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(ones)
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks, "allreduce_of_ones": float(ones),
+            "distinct_devices": len({(r["host"], r["device_index"]) for r in ranks}),
+            "launcher": "self (bench.py started torch.distributed.run)" if os.environ.get("FSW_BENCH_SELF_LAUNCHED") else "outer torch.distributed.run"}
+
+
+def weak_scaling_leg(args, x, ei, e_coalesced, dev, world, rank):
+    """BASELINE config 4's shape: the same graph with WEAK_SLICES_PER_GPU slices per GPU (1024 at 8 GPUs), i.e. per-GPU work
+    fixed as N grows.  N > 1: the consumer form (its collectives do not grow with the slice count)."""
+    from fsw_gnn_amd import FSW_conv
+    S = WEAK_SLICES_PER_GPU * world
+    ok, conv, st = True, None, {}
+    try:
+        torch.manual_seed(4321)
+        conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=S + 1, device=dev)
+        if world > 1:
+            conv.enable_slice_parallel(None, mode="consumer", chunks=args.chunks or None, output="replicated", stats=st)
+    except Exception as e:   # noqa: BLE001
+        ok, err = False, "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_ok(ok, dev, world):
+        return {"error": err if not ok else "another rank failed to set the leg up"}
+
+    def step():
+        with torch.no_grad():
+            return conv(x, ei)
+
+    elapsed, _ = timed_steps(step, args.warmup, args.steps, dev, world)
+    return {"scaling": "weak", "slices_per_gpu": WEAK_SLICES_PER_GPU, "slices": S, "n_gpus": world,
+            "ms_per_step": elapsed / args.steps * 1e3, "value": float(e_coalesced) * S * args.steps / elapsed,
+            "unit": "edges*slices/sec", "form": st.get("mode", "single GPU"), "collective": st.get("collective"),
+            "bytes_received_per_rank": st.get("bytes_received_per_rank")}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.environ["FSW_BENCH_SELF_LAUNCHED"] = "1"
+        sys.exit(self_launch(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d inside a launcher with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if world > 1:
+        # RCCL ("nccl") over xGMI, one rank per GPU.  FSW_BENCH_BACKEND=gloo is a functional rehearsal on a box with
+        # fewer GPUs than ranks (ranks then share a device; numbers from it mean nothing).
+        import datetime
+        backend = os.environ.get("FSW_BENCH_BACKEND", "nccl")
+        tmo = datetime.timedelta(seconds=300)    # a rank that died must not leave the others waiting for the default 10 minutes
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+
+    from fsw_gnn_amd import FSW_conv
+    from fsw_gnn_amd import dist as D
+    n, E = args.nodes, args.edges
+    embed_dim = args.slices + 1
+    x, ei = make_inputs(n, E, dev)
+    torch.manual_seed(4321)
+    conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=embed_dim, device=dev)
+    if args.no_fuse:
+        conv.fuse_linear = False
+    S = conv.fsw_embed.nSlices
+    keys = ei[1] * n + ei[0]
+    e_coalesced = int(torch.unique(keys).numel())          # E' of SURVEY 8(d): edges after the reference's coalesce()
+    del keys
+    wrec = world_record(dev, world, rank, local_rank)
+
+    def step():
+        with torch.no_grad():
+            return conv(x, ei)
+
+    forms, sp_stats = {}, {}
+    node_parallel = world > 1 and args.shard == "nodes" and not args.no_fuse
+    if world == 1:
+        elapsed, y = timed_steps(step, args.warmup, args.steps, dev, world)
+        assert torch.isfinite(y).all()
+        headline = None
+    elif node_parallel:
+        conv.enable_node_parallel(None)
+        elapsed, y = timed_steps(step, args.warmup, args.steps, dev, world)
+        assert torch.isfinite(y).all()
+        headline = None
+    else:
+        # every form over the same W + K steps; the headline is the fastest one that leaves the full output on every rank
+        for form in args.forms:
+            mode, output = FORM_ARGS[form]
+            st = {}
+            conv.enable_slice_parallel(None, mode=mode, chunks=args.chunks or None, output=output, stats=st)
+            el, y = timed_steps(step, args.warmup, args.steps, dev, world)
+            assert torch.isfinite(y[0] if isinstance(y, tuple) else y).all()
+            forms[form] = {"ms_per_step": el / args.steps * 1e3, "value": float(e_coalesced) * S * args.steps / el,
+                           "form_taken": st.get("mode"), "collective": st.get("collective"), "output": output,
+                           "bytes_sent_per_rank": st.get("bytes_sent_per_rank"),
+                           "bytes_received_per_rank": st.get("bytes_received_per_rank"), "_elapsed": el, "_stats": st}
+            del y
+        full = [f for f in args.forms if FORM_ARGS[f][1] == "replicated"] or list(args.forms)
+        headline = min(full, key=lambda f: forms[f]["_elapsed"])
+        elapsed, sp_stats = forms[headline]["_elapsed"], forms[headline]["_stats"]
 
     ms_per_step = elapsed / args.steps * 1e3
     value = float(e_coalesced) * S * args.steps / elapsed
+    cfg_name = {256: "BASELINE config 3", 1024: "BASELINE config 4 (1024 slices)"}.get(S, "config-3 graph, %d slices" % S)
     result = {
-        "metric": "edges*slices/sec FSW_conv forward, 1M-node/10M-edge, 256 slices", "value": value,
+        "metric": "edges*slices/sec FSW_conv forward, 1M-node/10M-edge, %d slices" % S, "value": value,
         "unit": "edges*slices/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: ER multigraph %d nodes / %d edges (%d after coalesce), %d feat, %d slices, "
+        "config": {"workload": "%s: ER multigraph %d nodes / %d edges (%d after coalesce), %d feat, %d slices, "
                                "FSW_conv(%d->%d, embed_dim=%d), full forward incl. CSR build and Linear layer"
-                               % (n, E, e_coalesced, D_FEAT, S, D_FEAT, OUT_CH, EMBED_DIM),
+                               % (cfg_name, n, E, e_coalesced, D_FEAT, S, D_FEAT, OUT_CH, embed_dim),
                    "nodes": n, "edges": E, "edges_coalesced": e_coalesced, "slices": S, "features": D_FEAT,
                    "parallelism": ("single GPU" if world == 1 else
-                                   "recipient-row shard x%d, all-gather of the output rows" % world if getattr(conv, "_node_parallel", False)
-                                   else "slice-axis shard x%d (%d slices per rank), %s form: %s" % (
-                                       world, S // world, sp_stats.get("mode", "?"), sp_stats.get("collective", "?")))},
+                                   "recipient-row shard x%d, all-gather of the output rows" % world if node_parallel
+                                   else "slice-axis shard x%d (%d slices per rank), headline = %s form: %s" % (
+                                       world, S // world, headline, sp_stats.get("collective", "?")))},
         # fraction of the 8 TB/s roofline for the WHOLE forward at SURVEY 8(d)'s 5.13 B per edge*slice (incl. CSR build)
         "path_roofline_frac": value * 5.13 / (HBM_PEAK_GBS * 1e9),
+        "world": wrec,
     }
     if rank == 0 and world == 1:
         roof, ms = dominant_kernel_roofline(conv, x, ei, n, e_coalesced, args.kernel_reps, dev)
         result["roofline"] = roof
         result["stage_ms"] = ms
+    if world > 1 and not node_parallel:
+        # the legs below only decorate the line (roofline of the sharded kernel, compute / collective split per form).  Local
+        # work sits in try blocks; before anything with a collective in it the ranks agree that all of them got there.
+        H = conv.mlp[0].out_features
+        width = 1 + max(b - a for a, b in D.slice_partition(S, world))
+        reps = max(3, args.kernel_reps // 4)
+        for form in args.forms:
+            f = forms[form]
+            st = f.pop("_stats")
+            f.pop("_elapsed")
+            mode, output = FORM_ARGS[form]
+            conv.enable_slice_parallel(None, mode=mode, chunks=args.chunks or None, output=output, stats={})
+            cms, err = 0.0, None
+            try:       # the same step with every collective replaced by a local copy = this rank's compute (no RCCL call inside)
+                D.COLLECTIVES_ENABLED = False
+                cms = timed_ms(step, reps, dev)
+            except Exception as e:   # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            finally:
+                D.COLLECTIVES_ENABLED = True
+            if all_ranks_ok(err is None, dev, world):
+                t = torch.tensor([cms], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                f["compute_ms"] = float(t)
+            else:
+                f["compute_ms_error"] = err or "another rank failed"
+            try:
+                coll = collectives_alone(st, n, H, width, world, reps, dev)
+            except Exception as e:   # noqa: BLE001 -- collectives_alone agrees across ranks before its first collective
+                coll = {"collective_error": "%s: %s" % (type(e).__name__, e)}
+            if coll:
+                f.update(coll)
+        result["forms"] = forms
+        result["headline_form"] = headline
+        for k in ("compute_ms", "collective_ms", "collective_GBps_per_rank", "bytes_sent_per_rank", "bytes_received_per_rank"):
+            if k in forms[headline]:
+                result[k] = forms[headline][k]
+        result["slice_parallel"] = {"mode": forms[headline].get("form_taken"), "collective": forms[headline].get("collective"),
+                                    "output": forms[headline]["output"]}
+        try:
+            roof = sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world,
+                                           forms[headline].get("form_taken") == "consumer")   # every rank runs it; no collective
+            if rank == 0:
+                result["roofline"] = roof
+        except Exception as e:   # noqa: BLE001 -- reported in the line, the headline number stands
+            result["extras_error"] = "%s: %s" % (type(e).__name__, e)
+    elif world > 1:
+        try:
+            roof = node_sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)
+            if rank == 0:
+                result["roofline"] = roof
+        except Exception as e:   # noqa: BLE001
+            result["extras_error"] = "%s: %s" % (type(e).__name__, e)
+    if not args.no_weak and not node_parallel and args.slices == N_SLICES:
+        del conv
+        torch.cuda.empty_cache()
+        result["weak_scaling"] = weak_scaling_leg(args, x, ei, e_coalesced, dev, world, rank)
+    if rank == 0 and world == 1:
         if not args.no_segcumsum:
-            del y
             torch.cuda.empty_cache()
             try:
                 result["segcumsum"] = segcumsum_leg(dev)
@@ -396,41 +612,13 @@ def main():
                 result["segcumsum"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, args.cpu_slices, args.cpu_threads)
+                torch.manual_seed(4321)
+                conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=embed_dim, device=dev)
+                result["cpu_baseline"] = cpu_baseline(x, ei, conv, n, min(args.cpu_slices, S), args.cpu_threads)
             except Exception as e:   # noqa: BLE001
                 result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if world > 1:
-        # the legs below only decorate the line (roofline of the sharded kernel, compute / collective split): a failure in
-        # one of them must not lose the timed result above
-        try:
-            if getattr(conv, "_node_parallel", False):
-                roof = node_sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world)
-            else:
-                from fsw_gnn_amd import dist as D
-                consumer = sp_stats.get("mode") == "consumer"
-                roof = sharded_kernel_roofline(conv, x, ei, n, max(3, args.kernel_reps // 2), dev, rank, world, consumer)   # every rank runs it
-                # the same step with every collective replaced by a local copy = this rank's compute
-                D.COLLECTIVES_ENABLED = False
-                cms = timed_ms(step, max(3, args.kernel_reps // 4), dev)
-                D.COLLECTIVES_ENABLED = True
-                t = torch.tensor([cms], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                result["compute_ms"] = float(t)
-                H = conv.mlp[0].out_features
-                width = 1 + max(b - a for a, b in D.slice_partition(S, world))
-                coll = collectives_alone(sp_stats, n, H, width, world, max(3, args.kernel_reps // 4), dev)
-                if coll:
-                    result.update(coll)
-                result["bytes_sent_per_rank"] = sp_stats.get("bytes_sent_per_rank")
-                result["bytes_received_per_rank"] = sp_stats.get("bytes_received_per_rank")
-                result["slice_parallel"] = {k: sp_stats.get(k) for k in ("mode", "collective")}
-                result["slice_parallel"]["output"] = args.output
-            if rank == 0:
-                result["roofline"] = roof
-        except Exception as e:   # noqa: BLE001 -- reported in the line, the headline number stands
-            result["extras_error"] = "%s: %s" % (type(e).__name__, e)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -77,15 +77,21 @@ __device__ __forceinline__ float mass_encode_f(float m, int fn) {
 }
 
 // phase 1 for one (degree, 64-slice chunk): embedding values of the block's rows into LDS (row_pipeline.h)
-template <int D>
+// RPW = rows per wavefront.  1: lane = slice of one row (col indices wave-uniform, scalar loads).  2: a slice block of at most
+// 32 slices (one rank's share of a slice-sharded layer at 8 ranks x 256 slices, dist.py) -- lanes 0..31 and 32..63 work on two
+// DIFFERENT rows of the same degree, so every lane gathers: the col indices become per-lane vector loads (two distinct
+// addresses per instruction), a gather instruction reads two 128-byte runs, the network and the FMAs are unchanged.
+template <int D, int RPW>
 __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int nrows, float* __restrict__ H, int chunk) {
+  constexpr int LPR = kWave / RPW;   // lanes per row
   const int lane = lane_id();
-  const int k = chunk * kWave + lane;
+  const int sub = RPW == 1 ? 0 : lane / LPR;
+  const int k = chunk * kWave + (RPW == 1 ? lane : lane % LPR);
   const bool kvalid = k < a.S;
   const int kc = kvalid ? k : a.S - 1;
   const float b = a.bias ? a.out_scale * a.bias[a.has_mass + kc] : 0.f;
   if constexpr (D == 0) {
-    for (int r = 0; r < nrows; ++r)
+    for (int r = sub; r < nrows; r += RPW)
       if (kvalid) H[r * a.ldh + a.has_mass + k] = b;
   } else {
     float coef[D];
@@ -95,14 +101,21 @@ __device__ __forceinline__ void fused_embed_rows(const FusedArgs& a, int p, int 
     const int startv = a.rowptr[a.perm[p + min(lane, nrows - 1)]];   // lane r: CSR offset of the block's row r
     float* hk = H + a.has_mass + kc;   // lanes past the last slice recompute slice S-1 (row_pipeline.h)
     const int ldh = a.ldh;
+    const int nsteps = (nrows + RPW - 1) / RPW;
+    // step r works on row r (RPW = 1) or on rows 2r and 2r + 1 (clamped to the last row: recomputed, same value stored again)
     pipelined_rows<D, pipeline_depth<D>(), FSW_FUSED_PIPE_BARRIER>(
-        nrows, a.col, a.Xp + kc, a.ldp, [&](int r) { return __builtin_amdgcn_readlane(startv, r); },
+        nsteps, a.col, a.Xp + kc, a.ldp,
+        [&](int r) {
+          if constexpr (RPW == 1) return __builtin_amdgcn_readlane(startv, r);
+          else return __shfl(startv, min(r * RPW + sub, nrows - 1));
+        },
         [&](KeyNet<D>& net, int r) {
           sort_network<D>(net);
           float acc = b;
 #pragma unroll
           for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
-          hk[r * ldh] = acc;
+          const int row = RPW == 1 ? r : min(r * RPW + sub, nrows - 1);
+          hk[row * ldh] = acc;
         });
   }
 }
@@ -148,7 +161,7 @@ __device__ __forceinline__ void slab_mma(const FusedArgs& a, const float* __rest
     if (g0 + u < ngroups) mma4(hp + 8 * (g0 + u), bq[u]);
 }
 
-template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0>  // ABL: timing experiments only (tools/exp_fused.py)
+template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0, int RPW = 1>  // ABL: timing experiments only (tools/exp_fused.py)
 __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* H = smem;                                                        // [kFusedRows][ldh]
@@ -198,7 +211,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
     switch (D) {
 #define X(d)                                                  \
   case d:                                                     \
-    if constexpr (d >= DLO && d <= DHI) fused_embed_rows<d>(a, p + r0, gn, H + r0 * a.ldh, chunk); \
+    if constexpr (d >= DLO && d <= DHI) fused_embed_rows<d, RPW>(a, p + r0, gn, H + r0 * a.ldh, chunk); \
     break;
       FSW_CASES_0_32(X)
 #undef X
@@ -367,7 +380,10 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   }
   FSW_ABL_CASE(1) FSW_ABL_CASE(2) FSW_ABL_CASE(4) FSW_ABL_CASE(6) FSW_ABL_CASE(7)
 #endif
-  k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4><<<(unsigned)nblocks, 256, lds, stream>>>(a);
+  if (e.S <= kWave / 2)   // a narrow slice block: two rows per wavefront (fused_embed_rows)
+    k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4, 0, 2><<<(unsigned)nblocks, 256, lds, stream>>>(a);
+  else
+    k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4><<<(unsigned)nblocks, 256, lds, stream>>>(a);
   FSW_LAUNCH_CHECK();
   return 0;
 }

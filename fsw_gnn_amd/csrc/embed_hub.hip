@@ -643,11 +643,7 @@ static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t
   rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
   if (rows_upper <= 0) return 0;
   const size_t lds = NW > 1 ? sizeof(float) * 2 * NW * M * kWave : 0;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_embed_hub_w<NW, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (lds > 64 * 1024) FSW_SET_MAX_LDS_ONCE((&k_embed_hub_w<NW, M>), lds);
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
   k_embed_hub_w<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, lds, stream>>>(

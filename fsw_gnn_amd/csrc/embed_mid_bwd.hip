@@ -150,12 +150,7 @@ int launch_mid_bwd_weighted(const fsw_embed_args& a, dim3 grid, const float* g, 
 #define FSW_MID_BWD(i, DP, WGT)                                                                                                   \
   do {                                                                                                                            \
     constexpr int lds = 4 * (DP) * kWave * (int)sizeof(float);                                                                    \
-    static bool attr_set = false;                                                                                                 \
-    if (!attr_set) {                                                                                                              \
-      FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_mid_bwd<DP, WGT>),                                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                        \
-      attr_set = true;                                                                                                            \
-    }                                                                                                                             \
+    FSW_SET_MAX_LDS_ONCE((k_embed_mid_bwd<DP, WGT>), lds);                                                                        \
     k_embed_mid_bwd<DP, WGT><<<grid, 256, lds, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp,  \
                                                          a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq,  \
                                                          a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk);                             \

@@ -96,7 +96,10 @@ __device__ __forceinline__ bool block_range(const int32_t* __restrict__ bin_star
 }
 
 // ---- unit weights ---------------------------------------------------------------------------------------
-template <int D>
+// RPW = rows per wavefront: 1 = lane is a slice of ONE row (col indices wave-uniform, scalar loads); 2 = a slice block of at
+// most 32 slices (one rank's share of a slice-sharded layer, dist.py): the two halves of the wavefront work on two different
+// rows of the same degree, so that every lane gathers (per-lane col loads, two 128-byte runs per gather instruction).
+template <int D, int RPW = 1>
 __device__ __forceinline__ void unit_run(int p, int pe, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                          const int32_t* __restrict__ perm, const float* __restrict__ Xp, int64_t ldp,
                                          const float* __restrict__ table, int64_t ldt, float* __restrict__ out, int64_t ldo,
@@ -109,20 +112,28 @@ __device__ __forceinline__ void unit_run(int p, int pe, const int32_t* __restric
   const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
   const int nrows = pe - p;
   const int lane = lane_id();
+  const int sub = RPW == 1 ? 0 : lane / (kWave / RPW);
   const int nodev = perm[p + min(lane, nrows - 1)];   // lane r: node id and CSR offset of the block's row r
   const int startv = rowptr[nodev];
   if (mass_lane_wave && lane < nrows)
     out[(int64_t)nodev * ldo] = out_scale * (mass_encode((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
-  // lanes past the last slice recompute slice S-1 and store the same value to the same address (row_pipeline.h)
+  // lanes past the last slice recompute slice S-1 and store the same value to the same address (row_pipeline.h); with RPW = 2 a
+  // step past the last row recomputes the last row in the same way
   float* ok = out + has_mass + kc;
+  const int nsteps = (nrows + RPW - 1) / RPW;
   pipelined_rows<D, pipeline_depth<D>(), FSW_REG_PIPE_BARRIER>(
-      nrows, col, Xp + kc, ldp, [&](int r) { return __builtin_amdgcn_readlane(startv, r); },
+      nsteps, col, Xp + kc, ldp,
+      [&](int r) {
+        if constexpr (RPW == 1) return __builtin_amdgcn_readlane(startv, r);
+        else return __shfl(startv, min(r * RPW + sub, nrows - 1));
+      },
       [&](KeyNet<D>& net, int r) {
         sort_network<D>(net);
         float acc = b;
 #pragma unroll
         for (int t = 0; t < D; ++t) acc = fmaf(coef[t], net.k[t], acc);
-        ok[(int64_t)__builtin_amdgcn_readlane(nodev, r) * ldo] = acc;
+        if constexpr (RPW == 1) ok[(int64_t)__builtin_amdgcn_readlane(nodev, r) * ldo] = acc;
+        else ok[(int64_t)__shfl(nodev, min(r * RPW + sub, nrows - 1)) * ldo] = acc;
       });
 }
 
@@ -148,6 +159,35 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit(const int32_t* __restric
   case d:                                                                                                             \
     unit_run<d>(p, pe, rowptr, col, perm, Xp, ldp, table, ldt, out, ldo, bias, out_scale, has_mass, mass_fn,          \
                 mass_scale, kc, has_mass && chunk == 0);                                                              \
+    break;
+    FSW_CASES_1_32(X)
+#undef X
+    default:
+      break;
+  }
+}
+
+// Narrow slice blocks (S <= 64): ONE 64-slice chunk exists, so instead of three waves of every workgroup leaving at once the four
+// waves split the workgroup's 32 rows; at S <= 32 two rows per wavefront step (unit_run<D, 2>).
+template <int RPW>
+__global__ void __launch_bounds__(256) k_embed_reg_unit_narrow(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
+                                                               const float* __restrict__ Xp, int64_t ldp, int S,
+                                                               const float* __restrict__ table, int64_t ldt, float* __restrict__ out,
+                                                               int64_t ldo, const float* __restrict__ bias, float out_scale,
+                                                               int has_mass, int mass_fn, float mass_scale) {
+  const int kc = min(lane_id() % (kWave / RPW), S - 1);
+  int D, p, pe;
+  if (!block_range(bin_start, D, p, pe)) return;
+  constexpr int kRowsPerWave = kRowsPerBlock / 4;
+  p += wave_id() * kRowsPerWave;
+  pe = min(pe, p + kRowsPerWave);
+  if (p >= pe) return;
+  switch (D) {
+#define X(d)                                                                                                          \
+  case d:                                                                                                             \
+    unit_run<d, RPW>(p, pe, rowptr, col, perm, Xp, ldp, table, ldt, out, ldo, bias, out_scale, has_mass, mass_fn,     \
+                     mass_scale, kc, has_mass != 0);                                                                  \
     break;
     FSW_CASES_1_32(X)
 #undef X
@@ -266,7 +306,13 @@ int launch_zero_rows(const fsw_embed_args& a, hipStream_t stream) {
 int launch_embed_reg(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
   dim3 grid((unsigned)(ceil_div(rows_upper, kRowsPerBlock) + FSW_REG_MAX_DEG), (unsigned)ceil_div(a.S, 4 * kWave));
-  if (unit_fast)
+  if (unit_fast && a.S <= kWave / 2)
+    k_embed_reg_unit_narrow<2><<<grid.x, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
+                                                          a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+  else if (unit_fast && a.S <= kWave)
+    k_embed_reg_unit_narrow<1><<<grid.x, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
+                                                          a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+  else if (unit_fast)
     k_embed_reg_unit<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
                                                a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
   else

@@ -453,12 +453,7 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
 
 template <int M, bool WEIGHTED>
 static int launch_wsort(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_wsort<M, WEIGHTED>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWsLdsBytes));
-    attr_set = true;
-  }
+  FSW_SET_MAX_LDS_ONCE((k_embed_wsort<M, WEIGHTED>), kWsLdsBytes);
   dim3 grid((unsigned)std::min<int64_t>(rows_upper, 1 << 14), kWsSplitY);
   k_embed_wsort<M, WEIGHTED><<<grid, 256, kWsLdsBytes, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp,
                                                                a.S, a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,

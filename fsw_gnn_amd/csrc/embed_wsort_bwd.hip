@@ -395,12 +395,7 @@ size_t embed_global_scratch_bytes(int64_t max_degree) {
 template <int M, bool WEIGHTED>
 static int launch_wsort_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, const float* g, int64_t ldg,
                             float* gXp, int64_t ldgp, float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_wsort_bwd<M, WEIGHTED>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, wb_lds_bytes<M, WEIGHTED>()));
-    attr_set = true;
-  }
+  FSW_SET_MAX_LDS_ONCE((k_embed_wsort_bwd<M, WEIGHTED>), (wb_lds_bytes<M, WEIGHTED>()));
   dim3 grid((unsigned)std::min<int64_t>(rows_upper, 1 << 14), kWbSplitY);
   k_embed_wsort_bwd<M, WEIGHTED><<<grid, 256, wb_lds_bytes<M, WEIGHTED>(), stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp,
                                                                    a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp, gfreq,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/fsw_hip.h"
 
 namespace fsw {
@@ -27,6 +28,22 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 #define FSW_LAUNCH_CHECK() FSW_CHECK_HIP(hipGetLastError())
+
+// Function attributes (the dynamic-LDS ceiling of a kernel) belong to a DEVICE: one flag per device ordinal and call site, so
+// a process that uses several GPUs sets them on each (racing host threads at worst set the same value twice).
+struct PerDeviceOnce {
+  std::atomic<bool> done[64];
+};
+#define FSW_SET_MAX_LDS_ONCE(kernel, bytes)                                                                          \
+  do {                                                                                                               \
+    static fsw::PerDeviceOnce once_;                                                                                 \
+    int dev_ = 0;                                                                                                    \
+    FSW_CHECK_HIP(hipGetDevice(&dev_));                                                                              \
+    if (dev_ < 0 || dev_ >= 64 || !once_.done[dev_].load(std::memory_order_relaxed)) {                               \
+      FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      if (dev_ >= 0 && dev_ < 64) once_.done[dev_].store(true, std::memory_order_relaxed);                           \
+    }                                                                                                                \
+  } while (0)
 
 constexpr int kWave = 64;
 

@@ -15,6 +15,7 @@
 // (A first version used one global int atomic per edge for the histogram and one for the scatter:
 //  1.13 ms at 10M edges against ~0.3 ms for the sort -- profiles/r01_v1_bench_kernel_stats.csv.)
 #include <algorithm>
+#include <atomic>
 #include "fsw_common.h"
 
 namespace fsw {
@@ -863,14 +864,7 @@ static int sort_and_finish_two_level(const int64_t* recipients, const int64_t* s
   const int64_t want = avg + avg / 32 + 256;   // random graphs: max bucket ~ avg + 4 sqrt(avg); a larger bucket scatters
   const int stage_cap = (want * (int64_t)sizeof(VAL) <= (int64_t)room) ? (int)(room / sizeof(VAL)) : 0;
   const size_t lds = tables + (size_t)stage_cap * sizeof(VAL);
-  static bool attr_set = false;
-  if (!attr_set) {
-    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 1024));
-    FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_rows<unsigned long long>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    attr_set = true;
-  }
+  FSW_SET_MAX_LDS_ONCE((&k_bucket_rows<VAL>), 160 * 1024 - 1024);
   k_bucket_rows<VAL><<<(unsigned)nbuckets, kBucketWaves * kWave, lds, stream>>>(g.keys[cur], reinterpret_cast<const VAL*>(g.vals[cur]), bstart,
                                                                               bstride, ntable, num_edges, num_rows, rb, rowptr, col, w,
                                                                               stage_cap);

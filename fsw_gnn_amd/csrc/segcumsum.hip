@@ -21,10 +21,12 @@
 // A head is an element whose id differs from its predecessor's (successor's when reverse != 0), exactly
 // the restart rule of segcumsum_slow (fsw_embedding.py:3016-3027).
 #include <algorithm>
+#include <atomic>
 #include "fsw_common.h"
 
 namespace fsw {
 
+constexpr int kMaxDevices = 64;
 constexpr int kSegThreads = 256;
 #ifndef FSW_SEG_WG_PER_CU
 #define FSW_SEG_WG_PER_CU 6
@@ -105,138 +107,190 @@ __device__ __forceinline__ unsigned desc_load(const unsigned long long* d, doubl
 }
 
 // ---- the single-pass kernel ----------------------------------------------------------------------------------
-// Data layout of a tile (TILE = 4 wavefronts x WCH elements): wavefront wv owns memory offsets [wv * WCH, (wv + 1) * WCH) of
-// the tile's memory range, and inside it lane l holds, for q < Q, the four elements q * 256 + 4 l .. 4 l + 3: every
-// wave-instruction reads or writes 64 x 16 B of CONSECUTIVE memory (32 B per lane for 8-byte items).  The scan runs in logical order,
-// which is memory order when !REV and the exact mirror image when REV (waves, q, lanes and the four elements of a lane
-// all descending), so one code path with mirrored indices serves both directions.
-// VEC: 16-byte accesses (pointers 16-byte aligned and the tile's memory range starting on a multiple of 4 elements).
-template <bool REV>
-__device__ __forceinline__ int logical_lane() { return REV ? kWave - 1 - lane_id() : lane_id(); }
-
-// value of the logically previous lane (undefined for logical lane 0)
-template <bool REV, class T>
-__device__ __forceinline__ T from_prev_lane(T v, int off = 1) { return REV ? __shfl_down(v, off) : __shfl_up(v, off); }
-
-template <bool REV, class V>
-__device__ __forceinline__ SegPair<V> wave_segscan_dir(SegPair<V> v) {
-  const int ll = logical_lane<REV>();
+// Data layout of a tile (TILE = 4 wavefronts x WCH elements).  Everything below is written in LOGICAL element order: logical
+// element L of the array sits at memory L when !REV and at memory n - 1 - L when REV, so a reverse scan is the same code with
+// mirrored addresses (no direction-dependent shuffle).  Wavefront w owns the logical range [w * WCH, (w + 1) * WCH) of its tile
+// and walks it in Q groups of 64 * EPL elements; in group q lane l holds the EPL consecutive elements q * 64 * EPL + l * EPL + u.
+// EPL = 16 bytes / the wider of (value, id): every load and store instruction of a wavefront covers ONE contiguous run of
+// memory (64 x 16 B for the wider type, 64 x 8 B for float32 values beside int64 ids) -- no instruction touches a fraction of
+// the lines it spans (the first layout of this kernel read int64 ids as two 16-byte pieces per lane at a 32-byte stride).
+// Cross-lane traffic is DPP only: row_shr 1/2/4/8 inside the rows of 16 lanes, row_bcast:15 and row_bcast:31 across them,
+// wave_shr:1 for the neighbour's last element; lanes without a source receive the monoid's identity (0, no head), so no
+// lane-index tests are needed.
+template <unsigned CTRL, unsigned ROW_MASK, class T>
+__device__ __forceinline__ T dpp_or_zero(T v) {
+  static_assert(sizeof(T) % 4 == 0, "32-bit pieces");
+  unsigned w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    SegPair<V> l;
-    l.s = from_prev_lane<REV>(v.s, off);
-    l.f = from_prev_lane<REV>(v.f, off);
-    if (ll >= off) v = seg_combine(l, v);
-  }
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w[i], CTRL, ROW_MASK, 0xf, false);
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+// lane `src` of a 4- or 8-byte value as a wave-uniform value (32-bit readlanes)
+template <class T>
+__device__ __forceinline__ T readlane_any(T v, int src) {
+  unsigned w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = (unsigned)__builtin_amdgcn_readlane((int)w[i], src);
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+constexpr unsigned kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <unsigned CTRL, unsigned ROW_MASK, class V>
+__device__ __forceinline__ SegPair<V> seg_dpp_step(SegPair<V> v) {
+  SegPair<V> l;
+  l.s = dpp_or_zero<CTRL, ROW_MASK>(v.s);
+  l.f = dpp_or_zero<CTRL, ROW_MASK>(v.f);
+  return seg_combine(l, v);
+}
+
+// inclusive segmented scan over the 64 lanes, lane order
+template <class V>
+__device__ __forceinline__ SegPair<V> wave_segscan_dpp(SegPair<V> v) {
+  v = seg_dpp_step<kDppRowShr + 1, 0xf>(v);
+  v = seg_dpp_step<kDppRowShr + 2, 0xf>(v);
+  v = seg_dpp_step<kDppRowShr + 4, 0xf>(v);
+  v = seg_dpp_step<kDppRowShr + 8, 0xf>(v);
+  v = seg_dpp_step<kDppRowBcast15, 0xa>(v);   // lane 15 -> row 1, lane 47 -> row 3
+  v = seg_dpp_step<kDppRowBcast31, 0xc>(v);   // lane 31 -> rows 2 and 3
   return v;
 }
+
+#ifndef FSW_SEG_PREFETCH
+#define FSW_SEG_PREFETCH 1   // issue the loads of the workgroup's next tile before the current tile is scanned
+#endif
+
+template <class V, class I>
+struct SegTile {
+  static constexpr int EPL = 16 / (int)(sizeof(V) > sizeof(I) ? sizeof(V) : sizeof(I));   // elements per lane and group
+  static constexpr int EPT = sizeof(V) == 4 ? 16 : 8;                                     // elements per thread and tile
+  static constexpr int Q = EPT / EPL;
+  static constexpr int GRP = kWave * EPL;                                                 // elements per group
+  static constexpr int WCH = kWave * EPT;                                                 // elements per wavefront and tile
+  static constexpr int NWV = kSegThreads / kWave;
+  static constexpr int TILE = NWV * WCH;
+  V val[Q][EPL];
+  I id[Q][EPL];
+  I idprev;          // id of the element logically just before this wavefront's chunk (wave-uniform)
+  bool has_prev;
+};
 
 template <class V, class I, bool REV, bool VEC>
 __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
                                                                  const I* __restrict__ ids, int64_t n,
                                                                  unsigned long long* __restrict__ desc, int64_t ntiles) {
-  constexpr int Q = sizeof(V) == 4 ? 4 : 2;           // 16 (float32) / 8 (float64) elements per thread
-  constexpr int WCH = kWave * 4 * Q;                  // elements per wavefront and tile
-  constexpr int NWV = kSegThreads / kWave;
-  constexpr int TILE = NWV * WCH;
+  using T = SegTile<V, I>;
+  constexpr int EPL = T::EPL, Q = T::Q, GRP = T::GRP, WCH = T::WCH, NWV = T::NWV, TILE = T::TILE;
   constexpr int DW = DescWords<V>::kWords;
+  typedef V vecv __attribute__((ext_vector_type(EPL)));
+  typedef I veci __attribute__((ext_vector_type(EPL)));
   __shared__ SegPair<V> wave_tot[NWV];
   __shared__ V carry_s;
   const int lane = lane_id(), wv = wave_id();
-  const int ll = logical_lane<REV>();
-  const int lwv = REV ? NWV - 1 - wv : wv;            // logical wave index
-  const int lastlane = REV ? 0 : kWave - 1;           // physical lane that is logically last
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // memory range of the tile: [M0, M0 + TILE); logical element L of the whole array sits at memory n - 1 - L when REV
-    const int64_t M0 = REV ? n - (tile + 1) * TILE : tile * TILE;
-    const int64_t mw = M0 + (int64_t)wv * WCH;        // this wavefront's memory range starts here
-    V val[Q][4];
-    I id[Q][4];
-    const bool whole = M0 >= 0 && M0 + TILE <= n;
+
+  // memory index of logical element L (L may lie past the end: the caller tests)
+  auto mem = [&](int64_t L) { return REV ? n - 1 - L : L; };
+  // logical index of the lane's first element of group q in `tile`
+  auto first_of = [&](int64_t tile, int q) { return tile * TILE + (int64_t)wv * WCH + q * GRP + lane * EPL; };
+
+  auto load_tile = [&](int64_t tile, T& t) {
+    const bool whole = (tile + 1) * TILE <= n;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int64_t m = mw + q * 256 + lane * 4;
+      const int64_t L = first_of(tile, q);
       if (VEC && whole) {
-        typedef V vecv __attribute__((ext_vector_type(4)));
-        typedef I veci __attribute__((ext_vector_type(4)));
-        const vecv tv = *reinterpret_cast<const vecv*>(values + m);
-        const veci ti = *reinterpret_cast<const veci*>(ids + m);
+        // the lane's EPL elements are contiguous in memory either way; reversed, the vector starts at the LAST logical one
+        const int64_t m0 = REV ? mem(L + EPL - 1) : L;
+        const vecv tv = *reinterpret_cast<const vecv*>(values + m0);
+        const veci ti = *reinterpret_cast<const veci*>(ids + m0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          val[q][u] = tv[u];
-          id[q][u] = ti[u];
+        for (int u = 0; u < EPL; ++u) {
+          t.val[q][u] = tv[REV ? EPL - 1 - u : u];
+          t.id[q][u] = ti[REV ? EPL - 1 - u : u];
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool ok = m + u >= 0 && m + u < n;
-          val[q][u] = ok ? values[m + u] : V(0);
-          id[q][u] = ok ? ids[m + u] : I(0);
+        for (int u = 0; u < EPL; ++u) {
+          const bool ok = L + u < n;
+          t.val[q][u] = ok ? values[mem(L + u)] : V(0);
+          t.id[q][u] = ok ? ids[mem(L + u)] : I(0);
         }
       }
     }
-    // id of the element logically just before this wavefront's chunk (wave-uniform)
-    const int64_t L0 = tile * TILE + (int64_t)lwv * WCH;          // first logical element of the chunk
-    const bool chunk_has_prev = L0 > 0 && L0 < n;
-    I idchunk = I(0);
-    if (chunk_has_prev) idchunk = ids[REV ? n - L0 : L0 - 1];
-    // heads and the lane-local scans, q in logical order
-    SegPair<V> pre[Q];      // everything of this wavefront's chunk that logically precedes the lane's four elements of q
+    const int64_t L0 = tile * TILE + (int64_t)wv * WCH;
+    t.has_prev = L0 > 0 && L0 < n;
+    t.idprev = t.has_prev ? ids[mem(L0 - 1)] : I(0);
+  };
+
+  T cur;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile, cur);
+  for (; tile < ntiles; tile += gridDim.x) {
+    // ---- heads (bit q * EPL + u) -- the ids are dead afterwards ----
+    unsigned heads = 0;
+    I carry_id = cur.idprev;                      // id logically before lane 0 of group q (wave-uniform)
+    bool carry_has = cur.has_prev;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      I idp = dpp_or_zero<kDppWaveShr1, 0xf>(cur.id[q][EPL - 1]);
+      bool hp = true;
+      if (lane == 0) {
+        idp = carry_id;
+        hp = carry_has;
+      }
+      const int64_t L = first_of(tile, q);
+#pragma unroll
+      for (int u = 0; u < EPL; ++u) {
+        const bool valid = L + u < n;
+        const bool head = valid && (u == 0 ? (!hp || cur.id[q][0] != idp) : cur.id[q][u] != cur.id[q][u - 1]);
+        heads |= (unsigned)head << (q * EPL + u);
+      }
+      carry_id = readlane_any(cur.id[q][EPL - 1], kWave - 1);   // the last lane's last id, wave-uniform
+      carry_has = true;
+    }
+    V val[Q][EPL];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int u = 0; u < EPL; ++u) val[q][u] = (first_of(tile, q) + u < n) ? cur.val[q][u] : V(0);
+#if FSW_SEG_PREFETCH
+    // the next tile of this workgroup: its loads are in flight while this tile is scanned, looked back and stored
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, cur);
+#endif
+    // ---- lane-local scans and the scan across the lanes, group by group ----
+    SegPair<V> pre[Q];      // everything of this wavefront's chunk that logically precedes the lane's elements of group q
     SegPair<V> wcarry;      // running aggregate of the chunk
     wcarry.s = V(0);
     wcarry.f = 0;
-    unsigned heads = 0;     // bit q * 4 + u
 #pragma unroll
-    for (int lq = 0; lq < Q; ++lq) {
-      const int q = REV ? Q - 1 - lq : lq;
-      const int ul = REV ? 0 : 3;                                  // logically last of the lane's four
-      // predecessor id of the lane's logically first element
-      I idp = from_prev_lane<REV>(id[q][ul]);
-      bool has_prev = true;
-      if (lq == 0) {
-        if (ll == 0) {
-          idp = idchunk;
-          has_prev = chunk_has_prev;
-        }
-      } else {
-        const int qp = REV ? q + 1 : q - 1;
-        const I wrap = __shfl(id[qp][ul], lastlane);
-        if (ll == 0) idp = wrap;
-      }
+    for (int q = 0; q < Q; ++q) {
       SegPair<V> agg;
       agg.s = V(0);
       agg.f = 0;
 #pragma unroll
-      for (int lu = 0; lu < 4; ++lu) {
-        const int u = REV ? 3 - lu : lu;
-        const int64_t m = mw + q * 256 + lane * 4 + u;
-        const bool valid = m >= 0 && m < n;
-        bool head;
-        if (lu == 0) head = !has_prev || id[q][u] != idp;
-        else head = id[q][u] != id[q][REV ? u + 1 : u - 1];
-        head = head && valid;
-        heads |= (unsigned)head << (q * 4 + u);
+      for (int u = 0; u < EPL; ++u) {
         SegPair<V> e;
-        e.s = valid ? val[q][u] : V(0);
-        e.f = head;
+        e.s = val[q][u];
+        e.f = (heads >> (q * EPL + u)) & 1u;
         agg = seg_combine(agg, e);
       }
-      const SegPair<V> inc = wave_segscan_dir<REV>(agg);            // inclusive over the lanes, logical order
+      const SegPair<V> inc = wave_segscan_dpp(agg);
       SegPair<V> ex;
-      ex.s = from_prev_lane<REV>(inc.s);
-      ex.f = from_prev_lane<REV>(inc.f);
-      if (ll == 0) {
-        ex.s = V(0);
-        ex.f = 0;
-      }
+      ex.s = dpp_or_zero<kDppWaveShr1, 0xf>(inc.s);
+      ex.f = dpp_or_zero<kDppWaveShr1, 0xf>(inc.f);
       pre[q] = seg_combine(wcarry, ex);
-      SegPair<V> tot;
-      tot.s = __shfl(inc.s, lastlane);
-      tot.f = __shfl(inc.f, lastlane);
+      SegPair<V> tot;     // the last lane's inclusive value, wave-uniform
+      tot.s = readlane_any(inc.s, kWave - 1);
+      tot.f = __builtin_amdgcn_readlane(inc.f, kWave - 1);
       wcarry = seg_combine(wcarry, tot);
     }
-    // across the wavefronts of the tile
-    if (lane == 0) wave_tot[lwv] = wcarry;
+    // ---- across the wavefronts of the tile ----
+    if (lane == 0) wave_tot[wv] = wcarry;
     __syncthreads();
     SegPair<V> wpre, tagg;
     wpre.s = V(0);
@@ -244,7 +298,7 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     tagg = wpre;
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
-      if (i == lwv) wpre = tagg;
+      if (i == wv) wpre = tagg;
       tagg = seg_combine(tagg, wave_tot[i]);
     }
     if (threadIdx.x == 0) {   // the tile's aggregate
@@ -286,30 +340,32 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     tc.s = carry_s;
     tc.f = 0;
     const SegPair<V> wenter = seg_combine(tc, wpre);               // everything before this wavefront's chunk
+    const bool whole = (tile + 1) * TILE <= n;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       V r = seg_combine(wenter, pre[q]).s;
-      V res[4];
+      V res[EPL];
 #pragma unroll
-      for (int lu = 0; lu < 4; ++lu) {
-        const int u = REV ? 3 - lu : lu;
-        r = ((heads >> (q * 4 + u)) & 1u) ? val[q][u] : r + val[q][u];
+      for (int u = 0; u < EPL; ++u) {
+        r = ((heads >> (q * EPL + u)) & 1u) ? val[q][u] : r + val[q][u];
         res[u] = r;
       }
-      const int64_t m = mw + q * 256 + lane * 4;
+      const int64_t L = first_of(tile, q);
       if (VEC && whole) {
-        typedef V vecv __attribute__((ext_vector_type(4)));
         vecv tv;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tv[u] = res[u];
-        *reinterpret_cast<vecv*>(out + m) = tv;
+        for (int u = 0; u < EPL; ++u) tv[REV ? EPL - 1 - u : u] = res[u];
+        *reinterpret_cast<vecv*>(out + (REV ? mem(L + EPL - 1) : L)) = tv;
       } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (m + u >= 0 && m + u < n) out[m + u] = res[u];
+        for (int u = 0; u < EPL; ++u)
+          if (L + u < n) out[mem(L + u)] = res[u];
       }
     }
     __syncthreads();   // carry_s / wave_tot are reused by the next tile
+#if !FSW_SEG_PREFETCH
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, cur);
+#endif
   }
 }
 
@@ -352,17 +408,25 @@ static int launch_segscan(const void* values, void* out, const void* ids, int64_
   FSW_CHECK_HIP(hipMemsetAsync(desc, 0, sizeof(unsigned long long) * DescWords<V>::kWords * (size_t)ntiles, stream));
   // persistent grid: every workgroup must be resident (the look-back spins on predecessors).  4 workgroups of 256
   // threads per CU need <= 128 registers and no LDS to speak of; the occupancy query guards against surprises.
-  static int grid_cache = 0;
-  if (!grid_cache) {
-    int dev = 0, cus = 0, per_cu = 0;
-    FSW_CHECK_HIP(hipGetDevice(&dev));
+  // The grid is a property of (kernel instantiation, DEVICE): one atomic slot per device ordinal, so a process that drives
+  // several GPUs -- or several host threads -- never sizes the grid of one device by another's CU count (a benign race:
+  // every writer stores the same value).
+  static std::atomic<int> grid_cache[kMaxDevices];
+  int dev = 0;
+  FSW_CHECK_HIP(hipGetDevice(&dev));
+  int resident = (dev >= 0 && dev < kMaxDevices) ? grid_cache[dev].load(std::memory_order_relaxed) : 0;
+  if (!resident) {
+    int cus = 0, per_cu = 0;
     FSW_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     FSW_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_segscan_chained<V, I, REV, true>, kSegThreads, 0));
-    grid_cache = std::max(1, cus) * std::max(1, std::min(per_cu - 1, kSegMaxWgPerCu));   // one below the query: it can be one high (MI355X guide)
+    resident = std::max(1, cus) * std::max(1, std::min(per_cu - 1, kSegMaxWgPerCu));   // one below the query: it can be one high (MI355X guide)
+    if (dev >= 0 && dev < kMaxDevices) grid_cache[dev].store(resident, std::memory_order_relaxed);
   }
-  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, grid_cache);
-  // 16-byte accesses: aligned pointers, and when scanning from the end the tiles must start on a multiple of 4 elements
-  const bool vec = ((uintptr_t)values % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)ids % 16 == 0) && (!REV || n % 4 == 0);
+  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, resident);
+  // vector accesses (EPL elements per lane): aligned pointers, and scanning from the end the groups must start on a multiple of EPL
+  constexpr int EPL = SegTile<V, I>::EPL;
+  const bool vec = ((uintptr_t)values % (EPL * sizeof(V)) == 0) && ((uintptr_t)out % (EPL * sizeof(V)) == 0) &&
+                   ((uintptr_t)ids % (EPL * sizeof(I)) == 0) && (!REV || n % EPL == 0);
   if (vec)
     k_segscan_chained<V, I, REV, true><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles);
   else
@@ -403,9 +467,17 @@ extern "C" int fsw_segcumsum(int value_dtype, const void* values, void* out, con
 }
 
 // ---- legacy ABI (reference fsw_embedding.cu:194, 212, 231): default stream, synchronous, void -----------
+// The reference synchronises the whole DEVICE before the launch and again after it (fsw_embedding.cu:197, 208, 215, 226).  The
+// first one is what makes its default-stream launch safe when the caller's producer work is queued on a NON-BLOCKING side
+// stream (torch's current stream need not be the null stream, and such a stream does not order itself against it).
+static bool legacy_sync_before(const char* what) {
+  const hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) fsw::set_error("%s: %s", what, hipGetErrorString(e));
+  return e == hipSuccess;
+}
 static void legacy_report(const char* what) {
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) fsw::set_error("%s: %s", what, hipGetErrorString(e));
 }
 
@@ -418,6 +490,7 @@ extern "C" void segcumsum_wrapper(int dtype, void* values, const int64_t* segmen
     fsw::set_error("segcumsum_wrapper: bad launch geometry");
     return;
   }
+  if (!legacy_sync_before("segcumsum_wrapper")) return;
   if (dtype == 0)
     k_legacy_block_scan<float><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(
         (float*)values, segment_ids, size, (float*)block_sums_out, block_last_ids_out, return_next_level);
@@ -433,6 +506,7 @@ extern "C" void add_block_sums_wrapper(int dtype, void* output, const void* bloc
     fsw::set_error("add_block_sums_wrapper: bad launch geometry");
     return;
   }
+  if (!legacy_sync_before("add_block_sums_wrapper")) return;
   if (dtype == 0)
     k_legacy_add_block_sums<float><<<(unsigned)num_blocks, (unsigned)threads_per_block, 0, nullptr>>>(
         (float*)output, (const float*)block_sums, segment_ids, block_last_id, size);

@@ -237,6 +237,9 @@ class FSW_conv(_Base):
         if n == 0:
             return torch.zeros((0, self.out_channels), dtype=vertex_features.dtype, device=vertex_features.device)
         if emb_mod.get_dtype() == torch.float64:
+            if getattr(self, '_node_parallel', False) or getattr(self, '_slice_parallel', None) is not None:
+                raise NotImplementedError("fsw_gnn_amd: slice / node sharding exists for float32 layers only (the float64 build runs "
+                                          "the generic kernels on one GPU)")
             # float64 build (the reference's test_conv.py runs the layer this way): the reference's own structure -- coalesced
             # COO adjacency and edge features (fsw_conv.py:384-447), FSW_embedding.forward on the generic kernels, torch tail
             adj, x_edge = self.adjacency_coo(edge_index, edge_features if self.edgefeat_dim > 0 else None, n, vertex_features.dtype)
@@ -379,6 +382,10 @@ class FSW_conv(_Base):
         if stats is not None:
             stats.clear()
         if needs_grad:
+            if sp['output'] == 'sharded' or sp['mode'] == 'consumer':
+                raise NotImplementedError("fsw_gnn_amd: training under slice sharding takes the differentiable gather form and returns "
+                                          "the replicated output; mode='consumer' / output='sharded' are inference forms "
+                                          "(call under torch.no_grad() or enable_slice_parallel(mode='auto'))")
             graph = self.build_graph(edge_index, n, edge_features if has_ef else None)
             ef_in = edge_features.reshape(edge_index.shape[1], -1) if has_ef else None
             emb = D.sharded_embed_autograd(emb_mod, x, graph, out_scale=1.0, group=group, edge_feat=ef_in)
@@ -400,9 +407,25 @@ class FSW_conv(_Base):
                 if stats is not None:
                     stats["mode"] = "consumer"
                 if sp['output'] == 'sharded':
+                    # R [chunks, rows_per_rank, H]: the remaining modules see ROWS x features (BatchNorm1d would take dim 1 of
+                    # a 3-D tensor for its channels), the pad rows past the last node are zeroed again afterwards
                     R, row0 = res
-                    for m in self.mlp[next_module:]:
-                        R = m(R)
+                    rest = self.mlp[next_module:]
+                    if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and (m.training or not m.track_running_stats)
+                           for m in rest):
+                        raise NotImplementedError("fsw_gnn_amd: output='sharded' with a BatchNorm layer in batch-statistics mode "
+                                                  "would normalise over this rank's rows only; call .eval() or use "
+                                                  "output='replicated'")
+                    if len(rest) > 0:
+                        shape = R.shape
+                        R2 = R.reshape(-1, shape[-1])
+                        for m in rest:
+                            R2 = m(R2)
+                        R = R2.reshape(shape[0], shape[1], -1)
+                        for c in range(shape[0]):
+                            valid = min(max(n - int(row0[c]), 0), shape[1])
+                            if valid < shape[1]:
+                                R[c, valid:] = 0
                     return R, row0
                 y = res
                 for m in self.mlp[next_module:]:

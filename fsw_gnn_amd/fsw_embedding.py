@@ -148,7 +148,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             gf = torch.zeros(S, dtype=torch.float32, device=X.device)
             a = module.make_args(graph, st, Xp, ldp, fr, S, table, None, 0, None, out_scale, has_mass, scratch, slice_offset=ka)
             nnz = st[_lib.STAT_NNZ]
-            if prepared["unit_fast"] and need_xp and 0 < nnz * S * 4 <= module.store_sum_backward_max_bytes:
+            if prepared["unit_fast"] and need_xp and 0 < nnz * S * 4 <= module.store_sum_budget(X.device):
                 # store-and-sum: every neighbour's key gradient is stored once (plain stores), then summed sender by sender over
                 # the sender-major entry list -- no float atomics, reproducible gradients
                 gkey = torch.empty((nnz, S), dtype=torch.float32, device=X.device)
@@ -711,6 +711,22 @@ class FSW_embedding(nn.Module):
     # backward of unit-weight graphs: store the key gradients ([nnz, nSlices] float32) and sum them sender by sender instead of
     # float atomics, as long as that buffer stays below this size (10.2 GB at 10M edges x 256 slices); 0 = always atomics
     store_sum_backward_max_bytes = 32 << 30
+    store_sum_free_memory_fraction = 0.25   # ... and below this share of the device memory that is free right now
+
+    def store_sum_budget(self, device):
+        """Bytes the transient [nnz, nSlices] key-gradient buffer of the store-and-sum backward may take: the fixed ceiling,
+        capped by a quarter of the currently free device memory (free in the driver's sense + what torch's caching allocator
+        holds unused), so that a training run that fits with the atomic backward never runs out of memory inside backward."""
+        cap = int(self.store_sum_backward_max_bytes)
+        if cap <= 0:
+            return 0
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+            cap = min(cap, int((free + max(cached, 0)) * self.store_sum_free_memory_fraction))
+        except Exception:   # noqa: BLE001 -- no query, keep the fixed ceiling
+            pass
+        return cap
     _force_plain = False   # embed_autograd: 'plain' mass column and no bias from the kernels, epilogue in torch
 
     def prepare(self, X, graph: CSRGraph, x_copy=None, linear2=None, slice_range=None):

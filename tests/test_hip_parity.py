@@ -767,6 +767,44 @@ def test_legacy_abi_drives_reference_hierarchy(dev):
     assert L.get_max_threads_per_block(0) == 1024
 
 
+def test_legacy_wrappers_wait_for_work_on_a_non_blocking_side_stream(dev):
+    """The reference's wrappers synchronise the DEVICE before they launch on the null stream (fsw_embedding.cu:197, 215): the
+    caller's producer may sit on a non-blocking side stream, which does not order itself against the null stream.  Here the
+    values are produced on such a stream behind ~100 ms of queued work and NOT synchronised by the caller."""
+    from fsw_gnn_amd import _lib
+    L = _lib.lib()
+    n, tpb = 1 << 16, 256
+    ids = torch.arange(n, device=dev, dtype=torch.int64) // 100              # segments of 100 <= tpb: one level suffices per block
+    side = torch.cuda.Stream(device=dev)                                      # torch side streams are created non-blocking
+    vals = torch.zeros(n, device=dev, dtype=torch.float32)
+    big = torch.randn((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        acc = big
+        for _ in range(60):
+            acc = acc @ big * 1e-2                                            # queued producer work
+        vals.fill_(1.0)                                                       # the values the scan must see
+    nblocks = n // tpb
+    sums = torch.empty(nblocks, device=dev, dtype=torch.float32)
+    last = torch.empty(nblocks, device=dev, dtype=torch.int64)
+    L.segcumsum_wrapper(0, vals.data_ptr(), ids.data_ptr(), n, 100, sums.data_ptr(), last.data_ptr(), True, nblocks, tpb, tpb * 4)
+    # the wrapper is synchronous like the reference's: the result is complete here without any caller-side synchronisation
+    got = vals.cpu().numpy()
+    i = np.arange(n)
+    want = np.minimum(i % 100, i % tpb) + 1.0                                 # block-local restart (the next level adds the carry)
+    assert np.array_equal(got, want)
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            acc = acc @ big * 1e-2
+        sums.fill_(1000.0)
+        last.copy_(ids[tpb - 1::tpb])
+    L.add_block_sums_wrapper(0, vals.data_ptr(), sums.data_ptr(), ids.data_ptr(), last.data_ptr(), n, nblocks, tpb)
+    got2 = vals.cpu().numpy()
+    carried = (i >= tpb) & ((i // 100) == ((i // tpb * tpb - 1) // 100))
+    assert np.array_equal(got2, want + 1000.0 * carried)
+    del acc
+
+
 # ---------------------------------------------------------------------------------------------------
 def _hip_projection(E, X):
     """float32 projections of the path under test (decide the sort order in the oracle: see fsw_embed_csr_backward)."""
@@ -1246,6 +1284,28 @@ with torch.no_grad():
         r0 = int(row0[c]); r1 = min(r0 + m, n)
         if r1 > r0:
             assert rel(R[c, :r1 - r0], ref[r0:r1]) < 1e-6
+    # 2b. sharded output of a layer whose tail is Linear -> BatchNorm1d -> act -> Linear: the remaining modules see [rows, H]
+    # (eval-mode BatchNorm is row-wise); pad rows past the last node come back as zeros; batch statistics mode is refused
+    torch.manual_seed(5)
+    conv2 = FSW_conv(d, 12, embed_dim=31, mlp_layers=2, mlp_hidden_dim=12, batchNorm_hidden=True, device=dev)
+    conv2.mlp[1].running_mean.copy_(torch.randn(12, device=dev) * 0.1)
+    conv2.mlp[1].running_var.copy_(torch.rand(12, device=dev) + 0.5)
+    conv2.eval()
+    ref_bn = conv2(X, ei)
+    conv2.enable_slice_parallel(None, mode="consumer", chunks=2, output="sharded")
+    Rb, row0b = conv2(X, ei)
+    assert Rb.dim() == 3 and Rb.shape[2] == 12
+    for c in range(Rb.shape[0]):
+        r0 = int(row0b[c]); r1 = min(r0 + Rb.shape[1], n)
+        if r1 > r0:
+            assert rel(Rb[c, :r1 - r0], ref_bn[r0:r1]) < 1e-5, rel(Rb[c, :r1 - r0], ref_bn[r0:r1])
+        assert not Rb[c, max(r1 - r0, 0):].any()
+    conv2.train()
+    try:
+        conv2(X, ei)
+        raise SystemExit("batch-statistics BatchNorm on a row shard must be refused")
+    except NotImplementedError:
+        pass
     # 3. auto on a graph with long rows: the consumer form does not apply, the gather form takes over
     ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
                      torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
@@ -1276,6 +1336,13 @@ assert rel(o2, o1) < 1e-6
 assert set(g1) == set(g2) and {"fsw_embed.projVecs", "fsw_embed.freqs", "mlp.0.weight", "X"} <= set(g1), sorted(g1)
 for k in g1:
     assert rel(g2[k], g1[k]) < 2e-4, (k, rel(g2[k], g1[k]))        # float atomics: the order of the sums differs run to run
+# inference-only forms are refused under autograd instead of silently returning the replicated gather form
+conv.enable_slice_parallel(None, mode="consumer", output="sharded")
+try:
+    conv(X.clone().requires_grad_(True), ei)
+    raise SystemExit("output='sharded' under autograd must be refused")
+except NotImplementedError:
+    pass
 conv.enable_slice_parallel(None, enabled=False)
 # node-range sharding (extra, behind its flag): every rank runs the fused layer on its rows, one all-gather of the OUTPUT
 conv.enable_node_parallel(None)

@@ -60,6 +60,35 @@ def test_homogeneity_edge_order_and_serialisation(dev, graph):
     assert torch.equal(_embed(emb, X, ei, n, serialize_num_slices=S // 4), base)
 
 
+@pytest.mark.parametrize("width", [5, 16, 32, 33, 64, 100])
+def test_slice_blocks_are_bit_identical_to_the_full_embedding(dev, width):
+    """Slice sharding (dist.py): a block of `width` slices computed alone equals the same columns of the full embedding bit for
+    bit, whatever kernel variant the width selects -- two rows per wavefront at <= 32 slices (every lane gathers), the four waves
+    of a workgroup splitting its rows at <= 64, the ordinary 64-slice chunks above -- on a graph with every degree 0..32 and
+    rows in every longer class, blocks at the start, in the middle and at the end of the slice axis."""
+    from fsw_gnn_amd import FSW_embedding, build_csr
+    n, d, S = 40_000, 24, 160
+    rng = np.random.default_rng(5)
+    deg = rng.integers(0, 34, n)                      # every degree 0..33
+    deg[:40] = [40, 64, 100, 200, 256, 300, 600, 1100, 2100, 5000] * 4
+    dst = np.repeat(np.arange(n), deg)
+    src = rng.integers(0, n, dst.size)
+    order = rng.permutation(dst.size)
+    ei = torch.from_numpy(np.stack([src[order], dst[order]])).to(dev)
+    X = torch.from_numpy(synth.features(n, d, 3)).to(dev)
+    torch.manual_seed(2)
+    emb = FSW_embedding(d, S + 1, device=dev, encode_total_mass=True)
+    with torch.no_grad():
+        graph = build_csr(ei[1], ei[0], None, n, n)
+        full = torch.empty((n, S + 1), device=dev)
+        emb.embed_into(X, graph, full)
+        for ka in (0, 37, S - width):
+            part = torch.full((n, 1 + width), float("nan"), device=dev)
+            emb.embed_into(X, graph, part, slice_range=(ka, ka + width))
+            assert torch.equal(part[:, 0], full[:, 0])
+            assert torch.equal(part[:, 1:], full[:, 1 + ka:1 + ka + width]), (width, ka)
+
+
 def test_duplicate_edges_equal_one_weighted_edge(dev):
     """k parallel unit edges == one edge of weight k (item 4), through the unit-table path on one side and the
     general-weight kernels on the other."""

@@ -241,3 +241,39 @@ def test_node_block_partition_covers_every_row_once():
             assert 0 <= nl <= per
             covered += list(range(r0, r0 + nl))
         assert covered == list(range(n))
+
+
+def test_bench_self_launch_command_and_relay(tmp_path, capfd):
+    """`python bench.py --gpus N` without a launcher: the parent builds the driver's own torch.distributed.run line
+    (one rank per GPU, 127.0.0.1 rendezvous), starts it as a CHILD process without touching the GPU itself, relays rank 0's
+    JSON line as the last stdout line and returns the child's exit code."""
+    import bench
+    argv = ["--gpus", "8", "--steps", "7", "--warmup", "2"]
+    cmd = bench.launch_command(argv, 8, 29517, script="/x/bench.py", python="python3")
+    assert cmd == ["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29517", "/x/bench.py"] + argv
+    args = bench.parse(argv)
+    assert args.gpus == 8 and args.forms == ["gather", "consumer"] and args.slices == 256
+    assert bench.parse(["--mode", "consumer", "--output", "sharded"]).forms == ["consumer_sharded"]
+    assert bench.parse(["--no-fuse"]).forms == ["gather"]
+    assert bench.parse(["--slices", "1024"]).slices == 1024
+    # the relay, with a stand-in for the rank program: two ranks, rank 0 prints the line, everybody prints noise
+    script = tmp_path / "fake_rank.py"
+    script.write_text(
+        "import os, sys\n"
+        "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
+        "print('noise from rank %d of %d' % (r, w), flush=True)\n"
+        "assert os.environ.get('MASTER_ADDR') == '127.0.0.1' and '--gpus' in sys.argv\n"
+        "if r == 0:\n"
+        "    print('{\"metric\": \"m\", \"n_gpus\": %d}' % w, flush=True)\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')) if r == 1 else 0)\n")
+    a2 = bench.parse(["--gpus", "2"])
+    rc = bench.self_launch(a2, ["--gpus", "2"], script=str(script))
+    out = capfd.readouterr()
+    assert rc == 0
+    assert out.out.strip().splitlines()[-1] == '{"metric": "m", "n_gpus": 2}' and "noise" not in out.out and "noise from rank 1 of 2" in out.err
+    os.environ["FAKE_RC"] = "3"
+    try:
+        assert bench.self_launch(a2, ["--gpus", "2"], script=str(script)) != 0      # a failing rank fails the run
+    finally:
+        del os.environ["FAKE_RC"]

@@ -13,15 +13,17 @@ from fsw_gnn_amd import dist as D
 ap = argparse.ArgumentParser()
 ap.add_argument("--mode", default="consumer")
 ap.add_argument("--chunks", type=int, default=0)
+ap.add_argument("--worlds", default="2,4,8")
+ap.add_argument("--slices", type=int, default=bench.N_SLICES)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 x, ei = bench.make_inputs(bench.N_NODES, bench.N_EDGES, dev)
 torch.manual_seed(4321)
-conv = FSW_conv(bench.D_FEAT, bench.OUT_CH, embed_dim=bench.EMBED_DIM, device=dev)
+conv = FSW_conv(bench.D_FEAT, bench.OUT_CH, embed_dim=args.slices + 1, device=dev)
 with torch.no_grad():
     print("single GPU: %.3f ms" % bench.timed_ms(lambda: conv(x, ei), 10, dev), flush=True)
     D.COLLECTIVES_ENABLED = False
-    for world in (2, 4, 8):
+    for world in [int(w) for w in args.worlds.split(',')]:
         dist.get_world_size = lambda group=None, w=world: w
         dist.get_rank = lambda group=None: 0
         for output in ("replicated", "sharded"):
