@@ -92,7 +92,8 @@ __device__ __forceinline__ void workgroup_merge_block(WaveLine<M, false>& ln, fl
 
 // unit-weight readout of the lane's M keys of ranks r0 .. r0 + M - 1 in a neighbourhood of D: coefficients
 // (1 + xi) [sin(2 pi xi (r + 1) / D) - sin(2 pi xi r / D)] / (pi xi) (reference fsw_embedding.py:1047-1075, 1109 with
-// weights 1 / D) by a float64 rotation started at the lane's first rank.  Returns the lane's partial sum.
+// weights 1 / D) = B cos(2 pi xi (r + 1/2) / D) by the one-FMA float64 recurrence of UnitCoef (fsw_common.h) started at the
+// lane's first rank.  Returns the lane's partial sum.
 template <int M, class Line>
 __device__ __forceinline__ float unit_readout(const Line& ln, int r0, int D, float xif) {
   const double xi = (double)xif;
@@ -103,20 +104,14 @@ __device__ __forceinline__ float unit_readout(const Line& ln, int r0, int D, flo
     for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
     return acc * 2.f * (float)inv;
   }
-  const double step = xi * inv;             // revolutions per rank
-  double sd, cd, s, c;
-  sincospi(2.0 * (step - rint(step)), &sd, &cd);
-  const double x0 = step * (double)r0;
-  sincospi(2.0 * (x0 - rint(x0)), &s, &c);
-  const double scale = (1.0 + xi) / (kPiH * xi);
+  UnitCoef uc;
+  uc.start(xi, D, r0);
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
-    acc += (r0 + j < D) ? (float)(scale * (sn - s)) * ln.k[j] : 0.f;
-    s = sn;
-    c = cn;
+    const float cj = uc.next();
+    acc += (r0 + j < D) ? cj * ln.k[j] : 0.f;
   }
-  return acc;
+  return acc * uc.B;
 }
 
 // gather elements t0 + j * 64 + lane (j < M; striped: lane-contiguous col reads -- the chunk is sorted next) of slice k
@@ -389,48 +384,69 @@ static int launch_hub_pair(const fsw_embed_args& a, int bin, int64_t rows_upper,
 }
 
 
-// ---- 257..512 neighbours: FOUR lines per wavefront, one per row of 16 lanes x 32 keys -----------------------------------------
-// With 16 lanes per line every cross-lane exchange of the merge levels is one DPP move inside a row (10 exchanges instead of the
-// 21 of a 64-lane line; the in-register part grows from 8 to 32 keys per lane, where a comparator costs one instruction per
-// key instead of two): ~0.8 instead of ~1.2 instructions per key.  The four lines are four adjacent slices of one row, so a
-// gather instruction reads 16 bytes from each of 16 rows of Xp instead of 4 bytes from 64.
-constexpr int kRowLanes = 16;
-
-template <int M>   // 32 keys per lane (512 per line), or 24 for the rows of at most 384 neighbours
-__global__ void __launch_bounds__(256, 4) k_embed_rowlines(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+// ---- 129..512 neighbours: SEVERAL lines per wavefront, LL lanes x M keys each ---------------------------------------------------
+// With LL <= 16 lanes per line every cross-lane exchange of the merge levels is one DPP move inside a row of 16 lanes, and more of
+// the network runs inside a lane (one instruction per key and comparator instead of two).  The 64 / LL lines of a wavefront are
+// adjacent slices of one row, so a gather instruction reads 64 / LL consecutive floats from each of LL rows of Xp.
+//   LL = 16, M = 32  : 257..512 neighbours (four lines per wavefront; a 64-lane line of 8 keys per lane ran 11.5 ms against 9.7)
+//   LL = 4, M = 48/64: 129..256 neighbours (16 lines per wavefront).  These rows used to run lane = slice with the whole row in one
+//                      lane's registers (embed_mid.hip: 160..256 keys -> one wave per SIMD, which can issue a vector instruction
+//                      only every 4 cycles and has nothing to overlap its gather with); split over four lanes the line takes
+//                      48..64 registers per lane and 3..4 waves per SIMD cover each other's gathers.
+template <int M, int LL>   // line = LL * M keys
+__global__ void __launch_bounds__(256, M <= 32 ? 4 : M <= 64 ? 3 : 2) k_embed_rowlines(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start, int bin,
                                                            const float* __restrict__ Xp, int64_t ldp, int S, const float* __restrict__ freqs,
                                                            float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
                                                            float out_scale, int has_mass, int mass_fn, float mass_scale, int dmin,
                                                            int dmax) {
-  constexpr int LPW = kWave / kRowLanes, LPB = 4 * LPW;   // lines per wavefront / per block
+  constexpr int LPW = kWave / LL, LPB = 4 * LPW;   // lines per wavefront / per block
   const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
-  const int lane = lane_id(), sub = lane & (kRowLanes - 1);
+  const int lane = lane_id(), sub = lane & (LL - 1);
   const int xcd = blockIdx.x & 7;
   for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
-    const int64_t i = (vb >> 3) * LPB + wave_id() * LPW + (lane >> 4);
+    const int64_t i = (vb >> 3) * LPB + wave_id() * LPW + lane / LL;
     const int64_t rl = i / S;
     const int k = (int)(i - rl * S);
     const int64_t r = rl * 8 + xcd;
-    if (r >= nrows) return;          // per row of 16 lanes; nothing below synchronises or crosses rows
+    if (r >= nrows) return;          // per group of LL lanes; nothing below synchronises or leaves the group
     const int node = perm[pbeg + r];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
-    if (D < dmin || D > dmax) continue;   // the 24- and the 32-key instantiation share the bin
-    WaveLine<M, false, false, kRowLanes> ln;
+    if (D < dmin || D > dmax) continue;   // instantiations of different line sizes may share a bin
+    WaveLine<M, false, false, LL> ln;
     const int32_t* colrow = col + start;
-    int c[M];
+    const float* xk = Xp + k;
+    // striped element order (lane-contiguous col reads; the line is sorted next).  Column indices one batch ahead of their gathers.
+    constexpr int G = M % 16 == 0 ? 16 : 8;
+    static_assert(M % G == 0, "keys per lane: a multiple of 8");
+    int c[2][G];
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const int t = j * kRowLanes + sub;
-      c[j] = t < D ? colrow[t] : -1;
+    for (int q = 0; q < G; ++q) {
+      const int t = q * LL + sub;
+      c[0][q] = t < D ? colrow[t] : -1;
     }
 #pragma unroll
-    for (int j = 0; j < M; ++j) ln.k[j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
+    for (int g = 0; g < M / G; ++g) {
+      if (g + 1 < M / G) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int t = ((g + 1) * G + q) * LL + sub;
+          c[(g + 1) & 1][q] = t < D ? colrow[t] : -1;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        const int cc = c[g & 1][q];
+        ln.k[g * G + q] = cc >= 0 ? xk[(int64_t)cc * ldp] : __builtin_inff();
+      }
+    }
     ln.sort();
     float tot = unit_readout<M>(ln, sub * M, D, freqs[k]);
-#pragma unroll
-    for (int off = kRowLanes / 2; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if constexpr (LL >= 16) tot += xor_lane<8>(tot);
+    if constexpr (LL >= 8) tot += xor_lane<4>(tot);
+    if constexpr (LL >= 4) tot += xor_lane<2>(tot);
+    if constexpr (LL >= 2) tot += xor_lane<1>(tot);
     if (sub == 0) {
       float* orow = out + (int64_t)node * ldo;
       orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
@@ -439,25 +455,43 @@ __global__ void __launch_bounds__(256, 4) k_embed_rowlines(const int32_t* __rest
   }
 }
 
-static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
-  constexpr int LPB = 4 * (kWave / kRowLanes);
+template <int M, int LL>
+static int launch_rowlines_one(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream, int dmin, int dmax) {
+  constexpr int LPB = 4 * (kWave / LL);
   rows_upper = bin_rows_or(a, bin, bin, rows_upper);
   if (rows_upper <= 0) return 0;
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
+  k_embed_rowlines<M, LL><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                                a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, dmin, dmax);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper, hipStream_t stream) {
   // rows of at most 384 neighbours on 24 keys per lane: off by default -- on a graph whose class sits near its upper end (the 64M-edge
   // RMAT graph: fill 0.93) the extra pass over the bin costs 0.8 ms and finds nothing
-  constexpr int kSmall = kRowLanes * 24;
+  constexpr int kSmall = 16 * 24;
   constexpr bool kSplit = FSW_HUB_SPLIT && FSW_ROWLINES_SPLIT;
-  if (kSplit) {
-    k_embed_rowlines<24><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
-                                                               a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, 0, kSmall);
-    FSW_LAUNCH_CHECK();
+  int rc;
+  if (kSplit && (rc = launch_rowlines_one<24, 16>(a, bin, rows_upper, stream, 0, kSmall))) return rc;
+  return launch_rowlines_one<32, 16>(a, bin, rows_upper, stream, kSplit ? kSmall + 1 : 0, 0x7fffffff);
+}
+
+// unit weights, mid bins of 129..256 neighbours (FSW_MID_SIZES 160 / 192 / 256): lines of 192 and 256 keys over LL lanes
+#ifndef FSW_MIDSPLIT_LL
+#define FSW_MIDSPLIT_LL 4
+#endif
+int launch_embed_mid_split(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  constexpr int LL = FSW_MIDSPLIT_LL;
+  constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
+  int rc;
+  for (int i = 0; i < FSW_NUM_MID_BINS; ++i) {
+    if (sizes[i] <= 128) continue;
+    if (sizes[i] <= 192) rc = launch_rowlines_one<192 / LL, LL>(a, FSW_BIN_MID0 + i, rows_upper, stream, 0, 0x7fffffff);
+    else rc = launch_rowlines_one<256 / LL, LL>(a, FSW_BIN_MID0 + i, rows_upper, stream, 0, 0x7fffffff);
+    if (rc) return rc;
   }
-  k_embed_rowlines<32><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
-                                                             a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
-                                                             kSplit ? kSmall + 1 : 0, 0x7fffffff);
-  FSW_LAUNCH_CHECK();
   return 0;
 }
 

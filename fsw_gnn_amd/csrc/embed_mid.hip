@@ -15,6 +15,7 @@
 //     cumulative weight and phase in float64 as in embed_reg.hip.
 #include "fsw_common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include "sortnet.h"
 
 namespace fsw {
@@ -47,7 +48,6 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
   const float xif = freqs[kc];
   const double xi = (double)xif;
   const bool lin = xif < 1e-30f;   // xi == 0: Delta_t = 2 w_t
-  const double scale = lin ? 0.0 : (double)out_scale * (1.0 + xi) / (kPiM * xi);
   const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
   const float* xk = Xp + kc;
   for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
@@ -68,20 +68,15 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
       for (int r = 0; r < DP; ++r)
         if (r < D) acc = fmaf(coef, net.k[r], acc);
     } else {
-      // s_r = sin(2 pi xi r / D) by rotation in float64: error ~ r * 2^-53
-      const double step = xi / (double)D;
-      double sd, cd;
-      sincospi(2.0 * (step - rint(step)), &sd, &cd);
-      double c = 1.0, s = 0.0;
+      // coefficient of rank r = B cos(2 pi xi (r + 1/2) / D): one float64 FMA per rank (UnitCoef, fsw_common.h)
+      UnitCoef uc;
+      uc.start(xi, D, 0);
+      float a2 = 0.f;
 #pragma unroll
       for (int r = 0; r < DP; ++r) {
-        if (r < D) {
-          const double sn = fma(s, cd, c * sd), cn = fma(c, cd, -(s * sd));
-          acc = fmaf((float)(scale * (sn - s)), net.k[r], acc);
-          s = sn;
-          c = cn;
-        }
+        if (r < D) a2 = fmaf(uc.next(), net.k[r], a2);
       }
+      acc = fmaf(out_scale * uc.B, a2, acc);
     }
     float* orow = out + (int64_t)node * ldo;
     orow[has_mass + kc] = acc;
@@ -171,6 +166,7 @@ __global__ void __launch_bounds__(256) k_embed_mid_weighted(const int32_t* __res
 int launch_mid_unit_small(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
 int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
 int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
+int launch_embed_mid_split(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);   // embed_hub.hip
 
 #define FSW_MID_UNIT(i, DP)                                                                                               \
   if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0)                                                            \
@@ -200,7 +196,10 @@ int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
   int rc;
   if (unit_fast) {
     if ((rc = launch_mid_unit_small(a, grid, stream))) return rc;
-    return launch_mid_unit_large(a, grid, stream);
+    // 129..256 neighbours: the line split over four lanes (embed_hub.hip: k_embed_rowlines<M, 4>); FSW_MID_SPLIT=0 in the environment
+    // brings back the one-lane-per-slice kernels for comparison (tools/exp_skew.py)
+    static const bool split = [] { const char* e = getenv("FSW_MID_SPLIT"); return !(e && e[0] == '0'); }();
+    return split ? launch_embed_mid_split(a, rows_upper, stream) : launch_mid_unit_large(a, grid, stream);
   }
   return launch_mid_weighted(a, grid, stream);   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the wave-sort path (embed_wsort.hip)
 }

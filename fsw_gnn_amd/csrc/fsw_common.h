@@ -77,6 +77,64 @@ __host__ __device__ inline uint32_t pow2ceil(uint32_t v) {
   return p;
 }
 
+// sin and cos of 2 pi x for x in REVOLUTIONS (|x| < 2^40), absolute error ~1e-15: reduction to [-1/8, 1/8] revolutions around the
+// nearest quarter turn (exact in float64), Taylor polynomials on |angle| <= pi/4, quadrant fix-up.  About a third of the
+// instructions of sincospi() -- the long-row kernels evaluate two of these per lane and row to start a recurrence.
+__device__ __forceinline__ void sincos_rev(double x, double* s, double* c) {
+  const double r = x - rint(x);                 // [-1/2, 1/2]
+  const double qd = rint(4.0 * r);              // -2 .. 2
+  const double a = (r - 0.25 * qd) * 6.283185307179586476925;
+  const double a2 = a * a;
+  double sp = 1.0 / 6227020800.0;
+  sp = fma(sp, a2, -1.0 / 39916800.0);
+  sp = fma(sp, a2, 1.0 / 362880.0);
+  sp = fma(sp, a2, -1.0 / 5040.0);
+  sp = fma(sp, a2, 1.0 / 120.0);
+  sp = fma(sp, a2, -1.0 / 6.0);
+  const double sa = fma(sp * a2, a, a);
+  double cp = -1.0 / 87178291200.0;
+  cp = fma(cp, a2, 1.0 / 479001600.0);
+  cp = fma(cp, a2, -1.0 / 3628800.0);
+  cp = fma(cp, a2, 1.0 / 40320.0);
+  cp = fma(cp, a2, -1.0 / 720.0);
+  cp = fma(cp, a2, 1.0 / 24.0);
+  cp = fma(cp, a2, -0.5);
+  const double ca = fma(cp, a2, 1.0);
+  const int q = (int)qd & 3;                    // angle = a + q pi / 2
+  const double s1 = (q & 1) ? ca : sa, c1 = (q & 1) ? sa : ca;
+  *s = (q & 2) ? -s1 : s1;
+  *c = (q == 1 || q == 2) ? -c1 : c1;
+}
+
+// Unit weights (c_t = t / D): coefficient of rank r in a neighbourhood of D at frequency xi,
+//   (1 + xi) [sin(2 pi xi (r + 1) / D) - sin(2 pi xi r / D)] / (pi xi)  =  B cos(2 pi step (r + 1/2)),   step = xi / D,
+//   B = (1 + xi) / (pi xi) * 2 sin(pi step)
+// (reference fsw_embedding.py:1047-1075, 1109 with weights 1 / D, by sum-to-product).  The cosines of consecutive ranks obey
+// c_{r+1} = 2 cos(2 pi step) c_r - c_{r-1}: ONE float64 FMA per rank (rounding error after m steps <= m^2 2^-53; every lane
+// restarts from exact values at its first rank).
+struct UnitCoef {
+  double twoc, cur, prev;   // 2 cos(2 pi step), cos(phi_r), cos(phi_{r-1}) for the next rank r
+  float B;
+  __device__ __forceinline__ void start(double xi, int D, int r0) {
+    const double step = xi / (double)D;          // revolutions per rank
+    double sh, ch, s0, c0;
+    sincos_rev(0.5 * step, &sh, &ch);
+    sincos_rev(step * ((double)r0 + 0.5), &s0, &c0);
+    const double sd = 2.0 * sh * ch, cd = fma(-2.0 * sh, sh, 1.0);
+    twoc = 2.0 * cd;
+    cur = c0;
+    prev = fma(c0, cd, s0 * sd);                 // cos(phi - theta)
+    B = (float)((1.0 + xi) / (3.14159265358979323846 * xi) * 2.0 * sh);
+  }
+  __device__ __forceinline__ float next() {     // cos(phi_r) of the current rank, then advance
+    const float v = (float)cur;
+    const double n = fma(twoc, cur, -prev);
+    prev = cur;
+    cur = n;
+    return v;
+  }
+};
+
 static_assert(FSW_NUM_LDS_BINS == 3 && FSW_MID_MAX_DEG == 256 && FSW_LDS_MAX_DEG == 2048, "degree_bin assumes LDS bins 512 / 1024 / 2048");
 static_assert(FSW_NUM_HUB_BINS == 4 && FSW_HUB_MAX_DEG == 32768, "degree_bin assumes hub bins 4096 / 8192 / 16384 / 32768");
 

@@ -161,6 +161,9 @@ __device__ __forceinline__ SegPair<V> wave_segscan_dpp(SegPair<V> v) {
   return v;
 }
 
+#ifndef FSW_SEG_ABL
+#define FSW_SEG_ABL 0   // timing experiments only: 1 no look-back (carry 0), 2 no scan (values stored as read), 4 ids not read
+#endif
 #ifndef FSW_SEG_PREFETCH
 #define FSW_SEG_PREFETCH 1   // issue the loads of the workgroup's next tile before the current tile is scanned
 #endif
@@ -207,7 +210,13 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
         // the lane's EPL elements are contiguous in memory either way; reversed, the vector starts at the LAST logical one
         const int64_t m0 = REV ? mem(L + EPL - 1) : L;
         const vecv tv = *reinterpret_cast<const vecv*>(values + m0);
-        const veci ti = *reinterpret_cast<const veci*>(ids + m0);
+        veci ti;
+        if constexpr (FSW_SEG_ABL & 4) {
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) ti[u] = (I)((m0 + u) / 10);
+        } else {
+          ti = *reinterpret_cast<const veci*>(ids + m0);
+        }
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
           t.val[q][u] = tv[REV ? EPL - 1 - u : u];
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     if (wv == 0) {
       V carry = V(0);
       int64_t t0 = tile - 1;
-      bool done = tile == 0;
+      bool done = tile == 0 || (FSW_SEG_ABL & 1);
       while (!done) {
         const int64_t t = t0 - lane;
         V dv = V(0);
@@ -348,7 +357,7 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
 #pragma unroll
       for (int u = 0; u < EPL; ++u) {
         r = ((heads >> (q * EPL + u)) & 1u) ? val[q][u] : r + val[q][u];
-        res[u] = r;
+        res[u] = (FSW_SEG_ABL & 2) ? val[q][u] : r;
       }
       const int64_t L = first_of(tile, q);
       if (VEC && whole) {

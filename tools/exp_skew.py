@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--weighted", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="", help="substring of the class name to time")
+    ap.add_argument("--fine", action="store_true", help="one line per degree BIN of the 33..256 class (padded sizes FSW_MID_SIZES)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n, S, d = 1 << args.scale, args.slices, args.feat
@@ -61,6 +62,9 @@ def main():
     classes = [("reg 1..32", 0, 32), ("mid 33..256", 32, 256), ("ws 257..512", 256, 512), ("ws 513..1024", 512, 1024),
                ("ws 1025..2048", 1024, 2048), ("hub 2049..4096", 2048, 4096), ("hub 4097..8192", 4096, 8192),
                ("hub 8193..16384", 8192, 16384), ("hub 16385..32768", 16384, 32768), ("global > 32768", 32768, 1 << 30)]
+    if args.fine:
+        edges_ = (32,) + tuple(_lib.MID_SIZES)
+        classes = [("mid %d..%d" % (a_ + 1, b_), a_, b_) for a_, b_ in zip(edges_[:-1], edges_[1:])] + classes[2:]
     for name, lo, hi in classes:
         if args.only and args.only not in name:
             continue
