@@ -314,9 +314,49 @@ __global__ void __launch_bounds__(256) k_pack_linear(const float* __restrict__ W
   }
 }
 
+// R[r, c] = act(R[r, c] + Yin[r, c] + bias[c]) in ONE launch: the epilogue of the slice-sharded layer forms (dist.py) on the rows a
+// rank owns after the reduce-scatter / all-to-all -- as separate torch ops (addmm_, add_, leaky_relu_) these 64 MB passes were four
+// launch-bound kernels per node-range chunk.
+__global__ void __launch_bounds__(256) k_add_bias_act(float* __restrict__ R, int64_t ldr, const float* __restrict__ Yin, int64_t ldyin,
+                                                      const float* __restrict__ bias, int64_t rows, int H, int act, float slope) {
+  const int hv = (H + 3) >> 2;   // float4 columns (callers guarantee 16-byte aligned rows when vec)
+  const int64_t total = rows * hv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / hv;
+    const int c = (int)(idx - r * hv) * 4;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c + u < H) {
+        float y = R[r * ldr + c + u];
+        if (Yin) y += Yin[r * ldyin + c + u];
+        if (bias) y += bias[c + u];
+        if (act == 1) y = fmaxf(y, 0.f);
+        else if (act == 2) y = y >= 0.f ? y : slope * y;
+        v[u] = y;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c + u < H) R[r * ldr + c + u] = v[u];
+  }
+}
+
 }  // namespace fsw
 
 using namespace fsw;
+
+extern "C" int fsw_add_bias_act_f32(float* R, int64_t ldr, const float* Yin, int64_t ldyin, const float* bias, int64_t rows, int H,
+                                    int act, float slope, fsw_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (rows == 0) return 0;
+  FSW_REQUIRE(R && rows > 0 && H >= 1 && ldr >= H && (!Yin || ldyin >= H), "fsw_add_bias_act_f32: bad arguments");
+  FSW_REQUIRE(act >= 0 && act <= 2, "fsw_add_bias_act_f32: act must be 0 (none), 1 (relu) or 2 (leaky relu)");
+  const int64_t total = rows * ((H + 3) / 4);
+  k_add_bias_act<<<(unsigned)std::min<int64_t>(ceil_div(total, 256), 4096), 256, 0, stream>>>(R, ldr, Yin, ldyin, bias, rows, H, act, slope);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" size_t fsw_packed_linear_floats(int K, int Hout) {
   return (size_t)(((K + 7) / 8) + 16) * (size_t)(((Hout + 31) / 32) * 32) * 8;

@@ -16,6 +16,12 @@ total-mass column are replicated (each rank builds the CSR itself).  Three ways 
             n x S embedding; the owner of a row block adds x . W2^T + b, applies the activation and one all-gather
             of the H-wide rows rebuilds the output.  No replicated GEMM, half the bytes of `gather` when H = S / 2, and
             output='sharded' stops after the reduce-scatter (the natural hand-over to a row-sharded next layer).
+  exchange  (any FSW_conv configuration the slice shard supports, any degree)  every rank embeds its slice block for ALL rows and
+            ONE all-to-all hands each row block to its owner: rank j receives, for the rows it owns, the slice blocks of all
+            ranks -- (G-1)/G of n x S/G floats per rank instead of the n x S of `gather` or the n x H partial sums of `consumer`
+            (S/G < H from 4 ranks on at BASELINE config 3: 112 MB against 448 MB at 8 ranks).  The owner lays the blocks side by
+            side (bit-identical to the single-GPU embedding rows), runs the whole tail (concat, MLP) on its rows, and one
+            all-gather of the out_channels-wide rows rebuilds the output; output='sharded' stops before it.
   training  `gather` through torch.autograd: the slice blocks are differentiated by this rank's backward kernels,
             block gradients are summed over the ranks inside backward (fsw_embedding._EmbedGraphFn), the replicated
             tail (MLP) computes identical gradients on every rank.
@@ -99,6 +105,21 @@ def _all_gather(out, inp, group, async_op):
         out[r * m:(r + 1) * m].copy_(inp)
         return _Done()
     w = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
+def _all_to_all(out, inp, group, async_op):
+    """out[j] <- block `rank` of rank j's inp, for every j (inp, out: [G, ...] contiguous, equal blocks)."""
+    if not COLLECTIVES_ENABLED:
+        out.copy_(inp)                            # the same bytes, moved locally
+        return _Done()
+    if inp.is_cuda and dist.get_backend(group) == "gloo":       # rehearsals with several gloo ranks on one GPU
+        world, r = dist.get_world_size(group), dist.get_rank(group)
+        big = torch.empty((world,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
+        dist.all_gather_into_tensor(big.view(world * inp.shape[0], *inp.shape[1:]), inp, group=group)
+        out.copy_(big[:, r])
+        return _Done()
+    w = dist.all_to_all_single(out, inp, group=group, async_op=async_op)
     return w if async_op else _Done()
 
 
@@ -338,15 +359,113 @@ def consumer_forward(conv, x, graph, prepared, scale, group=None, output="replic
         rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0.0, ybase, Pc.stride(0), stream)
         _lib.check(rc, "fsw_conv_fused_f32")
 
+    # x . W2^T + b of the rows this rank will own after the reduce-scatter (row block `rank` of every chunk): ONE gather of
+    # those rows of x and ONE GEMM, queued before the neighbourhood kernels -- nothing of it waits for a collective.  What is
+    # left behind the reduce-scatter is a single launch per chunk: R = act(R + own) (fsw_add_bias_act_f32).
+    m = cs // world
+    own = None
+    if W2 is not None:
+        pieces = []
+        for c in range(nchunks):
+            r0 = min(c * cs + rank * m, n)
+            r1 = min(r0 + m, n)
+            pieces.append(x[r0:r1])
+            if r1 - r0 < m:                                         # pad rows past the last node: never read back
+                pieces.append(x.new_zeros((m - (r1 - r0), x.shape[1])))
+        xo = torch.cat(pieces, dim=0) if len(pieces) > 1 else pieces[0]
+        own = (torch.addmm(lb, xo, W2.t()) if lb is not None else xo @ W2.t()).view(nchunks, m, H)
+
     def finish_rows(r0, r1, R):
-        if W2 is not None:
-            R.addmm_(x[r0:r1], W2.t())
-        if lb is not None:
-            R.add_(lb)
-        if act == 1:
-            R.relu_()
-        elif act == 2:
-            torch.nn.functional.leaky_relu(R, slope, inplace=True)
+        c = r0 // cs
+        yin = own[c] if own is not None else None
+        rc = L.fsw_add_bias_act_f32(_lib.ptr(R), R.stride(0), _lib.ptr(yin), yin.stride(0) if yin is not None else 0,
+                                    _lib.ptr(lb) if (own is None and lb is not None) else None, r1 - r0, H, act, slope, stream)
+        _lib.check(rc, "fsw_add_bias_act_f32")
 
     res = reduce_scatter_pipeline(compute_partial, finish_rows, nchunks, cs, n, H, x.dtype, x.device, group, output, stats)
     return res, next_module
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# exchange: all-to-all of the slice blocks, the tail on the rows a rank owns, all-gather of the output rows
+# ---------------------------------------------------------------------------------------------------------------------
+def all_to_all_pipeline(compute_block, finish_rows, num_chunks, chunk_rows, num_rows, w, H, dtype, device, group=None,
+                        output="replicated", stats=None):
+    """Chunk pipeline of the `exchange` form (pure choreography: the kernels come in as callables, so the CPU tests drive it
+    with the oracle).
+
+    compute_block(c, L_c)          fill L_c [chunk_rows, w] with this rank's slice block for the rows of chunk c
+    finish_rows(c, r0, r1, B, Y_c) B [G, m, w]: block j = rank j's slice block for the rows r0 .. r0 + m - 1 this rank owns in
+                                   chunk c (rows r1 .. are padding); write the finished rows into Y_c [m, H]
+    Chunk c is split in equal row blocks: rank r owns rows [c * cs + r * cs / G, c * cs + (r + 1) * cs / G).
+    output = 'replicated': one all-gather per chunk rebuilds Y [num_rows, H] on every rank (returned);
+    output = 'sharded'   : returns (R [num_chunks, cs / G, H], row0 [num_chunks]) -- this rank's finished rows.
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert chunk_rows % world == 0
+    m = chunk_rows // world
+    local = torch.empty((num_chunks, world, m, w), dtype=dtype, device=device)
+    recv = torch.empty((num_chunks, world, m, w), dtype=dtype, device=device)
+    if num_chunks * chunk_rows > num_rows:
+        local.view(-1, w)[num_rows:].zero_()
+    works = []
+    for c in range(num_chunks):
+        compute_block(c, local[c].view(chunk_rows, w))
+        works.append(_all_to_all(recv[c], local[c], group, async_op=num_chunks > 1))
+    R = torch.zeros((num_chunks, m, H), dtype=dtype, device=device)
+    Y = torch.empty((num_chunks * chunk_rows, H), dtype=dtype, device=device) if output == "replicated" else None
+    works2 = []
+    for c in range(num_chunks):
+        works[c].wait()
+        r0 = c * chunk_rows + rank * m
+        r1 = min(r0 + m, num_rows)
+        if r1 > r0:
+            finish_rows(c, r0, r1, recv[c], R[c])
+        if Y is not None:
+            works2.append(_all_gather(Y[c * chunk_rows:(c + 1) * chunk_rows], R[c], group, async_op=num_chunks > 1))
+    for wk in works2:
+        wk.wait()
+    if stats is not None:
+        esz = local.element_size()
+        a2a = num_chunks * chunk_rows * w * esz * (world - 1) // world
+        ag = num_chunks * chunk_rows * H * esz * (world - 1) // world if Y is not None else 0
+        stats["collective"] = "all_to_all" + ("+all_gather" if Y is not None else "")
+        stats["bytes_sent_per_rank"] = a2a + ag
+        stats["bytes_received_per_rank"] = a2a + ag
+    if Y is not None:
+        return Y[:num_rows]
+    row0 = torch.tensor([c * chunk_rows + rank * m for c in range(num_chunks)], dtype=torch.int64)
+    return R, row0
+
+
+def exchange_forward(conv, x, graph, prepared, scale, group=None, output="replicated", stats=None):
+    """FSW_conv's slice-sharded layer in the `exchange` form (module docstring): works for every configuration embed_into()
+    covers under slice sharding (unit or general weights, rows of any degree, any tail whose modules act row by row)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    emb = conv.fsw_embed
+    has_mass = 1 if emb.encode_total_mass else 0
+    parts = slice_partition(emb.nSlices, world)
+    ka, kb = parts[rank]
+    wmax = max(b - a for a, b in parts)
+    w = has_mass + wmax
+    n = graph.num_rows
+    cs, nchunks = (graph.chunk_rows, graph.num_chunks) if graph.chunk_rows else (round_chunk_rows(n, world), 1)
+    assert graph.chunk_rows or cs >= n
+    E = conv.embed_dim
+    width = E + conv.in_channels if conv.concat_self else E
+    H = conv.out_channels
+
+    def compute_block(c, lc):
+        if kb > ka:
+            emb.embed_into(x, graph, _RowWindow(lc, c * cs, n), out_scale=scale, prepared=prepared,
+                           chunks=[c if graph.chunk_rows else None])
+
+    def finish_rows(c, r0, r1, blocks, Yc):
+        rows = r1 - r0
+        buf = torch.empty((rows, width), dtype=x.dtype, device=x.device)
+        interleave_blocks(blocks[:, :rows], parts, has_mass, buf)          # the embedding rows, as on one GPU
+        if conv.concat_self:
+            buf[:, E:] = x[r0:r1]
+        Yc[:rows] = conv._tail_buffer(buf)
+
+    return all_to_all_pipeline(compute_block, finish_rows, nchunks, cs, n, w, H, x.dtype, x.device, group, output, stats)

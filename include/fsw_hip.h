@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
 
-#define FSW_ABI_VERSION 3
+#define FSW_ABI_VERSION 4
 
 /* Degree classes of the fused neighbourhood kernels.  Rows are binned by in-degree:
  *   bin b, 0 <= b <= FSW_REG_MAX_DEG : rows of degree exactly b (register path, one wave per row and
@@ -237,6 +237,12 @@ int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const 
                            int64_t ldy2, const int32_t* row_map, int32_t* stats, fsw_stream_t stream);
 int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
                        const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
+/* R[r, c] = act(R[r, c] + Yin[r, c] + bias[c]) for rows x H floats in place, one launch (Yin, bias may be NULL; act as in
+ * fsw_conv_fused_f32).  Epilogue of the slice-sharded layer forms (fsw_gnn_amd/dist.py): the rows a rank owns after the
+ * reduce-scatter of the partial sums receive x . W2^T + b (reference fsw_conv.py:357-362, the vertex-feature half of mlp[0]) and
+ * the activation.                                                                                                          */
+int fsw_add_bias_act_f32(float* R, int64_t ldr, const float* Yin, int64_t ldyin, const float* bias, int64_t rows, int H, int act,
+                         float slope, fsw_stream_t stream);
 
 /* ---- backward of the fused neighbourhood kernels (every weight mode and degree class) -----------------
  * Replaces the reverse-mode chain of the reference's sparse autograd Functions (ag.*.backward, reference
