@@ -50,6 +50,10 @@ WEAK_SLICES_PER_GPU = 128           # BASELINE config 4: 1024 slices sharded 128
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+FORM_ARGS = {"gather": ("gather", "replicated"), "consumer": ("consumer", "replicated"), "consumer_sharded": ("consumer", "sharded"),
+             "exchange": ("exchange", "replicated"), "exchange_sharded": ("exchange", "sharded")}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,24 +74,27 @@ def parse(argv=None):
     ap.add_argument("--shard", choices=("slices", "nodes"), default="slices",
                     help="N > 1: 'slices' = BASELINE north_star's slice-axis shard (default); 'nodes' = every rank runs the fused "
                          "layer on its block of recipient rows, all-gather of the 128-wide output (extra, not the contracted partition)")
-    ap.add_argument("--forms", default="gather,consumer",
+    ap.add_argument("--forms", default="gather,consumer,exchange",
                     help="N > 1, slice shard: comma-separated forms to time, each over the same K steps: 'gather' = north_star's "
                          "all-gather of the embedding, 'consumer' = sharded first Linear layer + reduce-scatter + all-gather of the "
-                         "output rows, 'consumer_sharded' = consumer stopping after the reduce-scatter (rows stay with their owner). "
+                         "output rows, 'exchange' = all-to-all of the slice blocks to the row owners + tail on the owned rows + all-gather of "
+                         "the output rows, 'consumer_sharded' / 'exchange_sharded' = the same without the final all-gather (rows stay "
+                         "with their owner). "
                          "The headline value is the fastest form that returns the full output on every rank.")
-    ap.add_argument("--mode", choices=("auto", "consumer", "gather"), default=None,
-                    help="(older spelling) time ONE form: consumer / gather; auto = consumer")
+    ap.add_argument("--mode", choices=("auto", "consumer", "gather", "exchange"), default=None,
+                    help="(older spelling) time ONE form: consumer / gather / exchange; auto = consumer")
     ap.add_argument("--chunks", type=int, default=0, help="node-range chunks of the multi-GPU pipeline (0 = by size)")
     ap.add_argument("--output", choices=("replicated", "sharded"), default="replicated",
                     help="with --mode consumer: 'sharded' stops after the reduce-scatter (every rank keeps its finished rows)")
     args = ap.parse_args(argv)
     if args.mode is not None:
-        args.forms = "gather" if args.mode == "gather" else ("consumer_sharded" if args.output == "sharded" else "consumer")
+        base = "consumer" if args.mode == "auto" else args.mode
+        args.forms = base + ("_sharded" if args.output == "sharded" and base != "gather" else "")
     if args.no_fuse:
-        args.forms = "gather"
+        args.forms = "gather,exchange"
     args.forms = [f for f in args.forms.split(",") if f]
     for f in args.forms:
-        if f not in ("gather", "consumer", "consumer_sharded"):
+        if f not in FORM_ARGS:
             ap.error("unknown form %r" % f)
     return args
 
@@ -278,6 +285,17 @@ def collectives_alone(stats, n, H, width, world, reps, dev):
                 D._reduce_scatter(R, P, None, False)
                 if "all_gather" in stats.get("collective", ""):
                     D._all_gather(P, R, None, False)
+        elif stats.get("mode") == "exchange":
+            rows = -(-n // world) * world
+            A = torch.zeros((world, rows // world, width), dtype=torch.float32, device=dev)
+            B = torch.empty_like(A)
+            R = torch.zeros((rows // world, H), dtype=torch.float32, device=dev)
+            Y = torch.empty((rows, H), dtype=torch.float32, device=dev)
+
+            def fn():
+                D._all_to_all(B, A, None, False)
+                if "all_gather" in stats.get("collective", ""):
+                    D._all_gather(Y, R, None, False)
         else:
             loc = torch.zeros((n, width), dtype=torch.float32, device=dev)
             flat = torch.empty((world * n, width), dtype=torch.float32, device=dev)
@@ -406,7 +424,7 @@ def all_ranks_ok(ok, dev, world):
     return int(t) == 0
 
 
-FORM_ARGS = {"gather": ("gather", "replicated"), "consumer": ("consumer", "replicated"), "consumer_sharded": ("consumer", "sharded")}
+
 
 
 def world_record(dev, world, rank, local_rank):

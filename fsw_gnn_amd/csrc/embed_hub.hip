@@ -26,7 +26,7 @@ namespace fsw {
 constexpr double kPiH = 3.14159265358979323846;
 [[maybe_unused]] constexpr int kHubM = 32;                  // keys per lane
 #ifndef FSW_HUB_ABL
-#define FSW_HUB_ABL 0   // timing experiments (tools/exp_hub.sh): 1 no gather, 2 no wave sort, 4 no cross-wave merge
+#define FSW_HUB_ABL 0   // timing experiments (tools/exp_hub.sh): 1 no gather, 2 no wave sort, 4 no cross-wave merge, 8 no readout
 #endif
 
 __device__ __forceinline__ float mass_encode_h(float m, int fn) {
@@ -103,6 +103,11 @@ __device__ __forceinline__ float unit_readout(const Line& ln, int r0, int D, flo
 #pragma unroll
     for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
     return acc * 2.f * (float)inv;
+  }
+  if constexpr (FSW_HUB_ABL & 8) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) acc += (r0 + j < D) ? ln.k[j] : 0.f;
+    return acc;
   }
   UnitCoef uc;
   uc.start(xi, D, r0);
@@ -438,10 +443,10 @@ __global__ void __launch_bounds__(256, M <= 32 ? 4 : M <= 64 ? 3 : 2) k_embed_ro
 #pragma unroll
       for (int q = 0; q < G; ++q) {
         const int cc = c[g & 1][q];
-        ln.k[g * G + q] = cc >= 0 ? xk[(int64_t)cc * ldp] : __builtin_inff();
+        ln.k[g * G + q] = cc >= 0 ? ((FSW_HUB_ABL & 1) ? (float)((cc * 2654435761u) >> 8) : xk[(int64_t)cc * ldp]) : __builtin_inff();
       }
     }
-    ln.sort();
+    if (!(FSW_HUB_ABL & 2)) ln.sort();
     float tot = unit_readout<M>(ln, sub * M, D, freqs[k]);
     if constexpr (LL >= 16) tot += xor_lane<8>(tot);
     if constexpr (LL >= 8) tot += xor_lane<4>(tot);

@@ -196,9 +196,11 @@ int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
   int rc;
   if (unit_fast) {
     if ((rc = launch_mid_unit_small(a, grid, stream))) return rc;
-    // 129..256 neighbours: the line split over four lanes (embed_hub.hip: k_embed_rowlines<M, 4>); FSW_MID_SPLIT=0 in the environment
-    // brings back the one-lane-per-slice kernels for comparison (tools/exp_skew.py)
-    static const bool split = [] { const char* e = getenv("FSW_MID_SPLIT"); return !(e && e[0] == '0'); }();
+    // 129..256 neighbours: FSW_MID_SPLIT=1 in the environment runs the line split over four lanes instead (embed_hub.hip:
+    // k_embed_rowlines<M, 4>, three waves per SIMD).  Measured SLOWER on the populated bin of the RMAT graphs (129..160 neighbours:
+    // 373 against 524 G keys/s; LL = 2 / 8: 379 / 392): four 64-byte pieces per gather instruction instead of one 256-byte run
+    // cost more than the occupancy gains -- kept for comparison (tools/exp_skew.py --fine)
+    static const bool split = [] { const char* e = getenv("FSW_MID_SPLIT"); return e && e[0] == '1'; }();
     return split ? launch_embed_mid_split(a, rows_upper, stream) : launch_mid_unit_large(a, grid, stream);
   }
   return launch_mid_weighted(a, grid, stream);   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the wave-sort path (embed_wsort.hip)

@@ -164,6 +164,9 @@ __device__ __forceinline__ SegPair<V> wave_segscan_dpp(SegPair<V> v) {
 #ifndef FSW_SEG_ABL
 #define FSW_SEG_ABL 0   // timing experiments only: 1 no look-back (carry 0), 2 no scan (values stored as read), 4 ids not read
 #endif
+#ifndef FSW_SEG_HALO
+#define FSW_SEG_HALO 1    // carry from the previous tile's last group when it holds a segment head (no descriptor round trip)
+#endif
 #ifndef FSW_SEG_PREFETCH
 #define FSW_SEG_PREFETCH 1   // issue the loads of the workgroup's next tile before the current tile is scanned
 #endif
@@ -181,6 +184,8 @@ struct SegTile {
   I id[Q][EPL];
   I idprev;          // id of the element logically just before this wavefront's chunk (wave-uniform)
   bool has_prev;
+  V hval[EPL];       // wavefront 0 only: the HALO, the last group of 64 * EPL elements of the previous tile (lane l: its elements
+  I hid[EPL];        // l * EPL .. of that group) -- see the look-back
 };
 
 template <class V, class I, bool REV, bool VEC>
@@ -234,6 +239,25 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     const int64_t L0 = tile * TILE + (int64_t)wv * WCH;
     t.has_prev = L0 > 0 && L0 < n;
     t.idprev = t.has_prev ? ids[mem(L0 - 1)] : I(0);
+    if (FSW_SEG_HALO && wv == 0 && tile > 0) {      // wave-uniform; the halo lies wholly inside the array (tile * TILE <= n - 1)
+      const int64_t L = tile * TILE - GRP + lane * EPL;
+      if (VEC) {
+        const int64_t m0 = REV ? mem(L + EPL - 1) : L;
+        const vecv tv = *reinterpret_cast<const vecv*>(values + m0);
+        const veci ti = *reinterpret_cast<const veci*>(ids + m0);
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+          t.hval[u] = tv[REV ? EPL - 1 - u : u];
+          t.hid[u] = ti[REV ? EPL - 1 - u : u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+          t.hval[u] = values[mem(L + u)];
+          t.hid[u] = ids[mem(L + u)];
+        }
+      }
+    }
   };
 
   T cur;
@@ -267,6 +291,29 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int u = 0; u < EPL; ++u) val[q][u] = (first_of(tile, q) + u < n) ? cur.val[q][u] : V(0);
+    // The halo (wavefront 0): when the last group of the previous tile holds a segment head, the sum from that head to the end of
+    // the previous tile IS the carry into this tile -- the value the predecessor publishes as its aggregate, formed by the same
+    // operations in the same order -- and it depends on nothing but 64 * EPL elements this wavefront has just read itself.  With
+    // neighbourhood-sized segments that is every tile: the look-back below (a descriptor round trip through the fabric, ~2 us that
+    // the whole workgroup waits for: 26 % of the kernel at 2.56e8 elements) then never runs.  Tiles keep publishing their
+    // descriptors: a tile whose halo holds no head (segments longer than 64 * EPL) falls back to them.  The first halo element counts
+    // as "no head" (its predecessor is not read): conservative.
+    SegPair<V> halo;
+    halo.s = V(0);
+    halo.f = 0;
+    if (FSW_SEG_HALO && wv == 0 && tile > 0) {
+      const I idp = dpp_or_zero<kDppWaveShr1, 0xf>(cur.hid[EPL - 1]);
+#pragma unroll
+      for (int u = 0; u < EPL; ++u) {
+        SegPair<V> e;
+        e.s = cur.hval[u];
+        e.f = u == 0 ? (lane > 0 && cur.hid[0] != idp) : (cur.hid[u] != cur.hid[u - 1]);
+        halo = seg_combine(halo, e);
+      }
+      halo = wave_segscan_dpp(halo);
+      halo.s = readlane_any(halo.s, kWave - 1);
+      halo.f = __builtin_amdgcn_readlane(halo.f, kWave - 1);
+    }
 #if FSW_SEG_PREFETCH
     // the next tile of this workgroup: its loads are in flight while this tile is scanned, looked back and stored
     if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, cur);
@@ -316,9 +363,9 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     }
     // decoupled look-back by wavefront 0: 64 predecessors per step, newest in lane 0
     if (wv == 0) {
-      V carry = V(0);
+      V carry = halo.f ? halo.s : V(0);
       int64_t t0 = tile - 1;
-      bool done = tile == 0 || (FSW_SEG_ABL & 1);
+      bool done = tile == 0 || halo.f || (FSW_SEG_ABL & 1);
       while (!done) {
         const int64_t t = t0 - lane;
         V dv = V(0);

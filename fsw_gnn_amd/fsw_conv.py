@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from .coherence import minimize_mutual_coherence
 from .fsw_embedding import FSW_embedding
-from .graph import build_csr, build_csr_coalesced
+from .graph import BuildHint, build_csr, build_csr_coalesced
 
 try:  # optional dependency, exactly the names the reference imports (fsw_conv.py:4-9)
     from torch_geometric.nn import MessagePassing as _Base
@@ -210,7 +210,8 @@ class FSW_conv(_Base):
             deg = torch.zeros(num_vertices, device=src.device, dtype=torch.float32).scatter_add_(0, dst, w)
             ds = torch.sqrt(deg)
             w = w / ds[dst] / ds[src]
-        return build_csr(dst, src, w, num_vertices, num_vertices, want_invperm=self._fusable(), chunk_rows=chunk_rows)
+        return build_csr(dst, src, w, num_vertices, num_vertices, want_invperm=self._fusable(), chunk_rows=chunk_rows,
+                         hint=self._build_hint())
 
     def forward(self, vertex_features, edge_index, edge_features=None):
         """vertex_features [n, in_channels], edge_index [2, E] long -> [n, out_channels] (fsw_conv.py:331-369)."""
@@ -382,9 +383,9 @@ class FSW_conv(_Base):
         if stats is not None:
             stats.clear()
         if needs_grad:
-            if sp['output'] == 'sharded' or sp['mode'] == 'consumer':
+            if sp['output'] == 'sharded' or sp['mode'] in ('consumer', 'exchange'):
                 raise NotImplementedError("fsw_gnn_amd: training under slice sharding takes the differentiable gather form and returns "
-                                          "the replicated output; mode='consumer' / output='sharded' are inference forms "
+                                          "the replicated output; mode='consumer' / 'exchange' / output='sharded' are inference forms "
                                           "(call under torch.no_grad() or enable_slice_parallel(mode='auto'))")
             graph = self.build_graph(edge_index, n, edge_features if has_ef else None)
             ef_in = edge_features.reshape(edge_index.shape[1], -1) if has_ef else None
@@ -436,8 +437,22 @@ class FSW_conv(_Base):
                                           % _lib.REG_MAX_DEG)
         elif mode == 'consumer' and world > 1:
             raise NotImplementedError("fsw_gnn_amd: the sharded-consumer form needs the fused configuration (csrc/conv_fused.hip)")
+        if world > 1 and mode == 'exchange':
+            # all-to-all of the slice blocks to the owners of the rows, the whole tail on the owned rows (dist.py)
+            tail_mods = list(self.mlp) if self.mlp is not None else []
+            if self.bn_final is not None:
+                tail_mods.append(self.bn_final)
+            if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and (m.training or not m.track_running_stats) for m in tail_mods):
+                raise NotImplementedError("fsw_gnn_amd: the exchange form runs the tail on this rank's rows only; a BatchNorm layer in "
+                                          "batch-statistics mode needs all rows (call .eval() or use mode='gather')")
+            if prepared is None:
+                prepared = emb_mod.prepare(x, graph, slice_range=parts[rank])
+            res = D.exchange_forward(self, x, graph, prepared, scale, group, sp['output'], stats)
+            if stats is not None:
+                stats["mode"] = "exchange"
+            return res
         if sp['output'] == 'sharded':
-            raise NotImplementedError("fsw_gnn_amd: output='sharded' exists for the sharded-consumer form only")
+            raise NotImplementedError("fsw_gnn_amd: output='sharded' exists for the consumer and exchange forms only")
         if self._split_first_linear():      # the same tail as on one GPU, so the gathered layer stays bit-identical to it
             emb = torch.empty((n, E), dtype=x.dtype, device=x.device)
             D.sharded_embed_into(emb_mod, x, graph, emb, out_scale=scale, group=group, x_copy=None, prepared=prepared, stats=stats)
@@ -453,6 +468,14 @@ class FSW_conv(_Base):
         return self._tail_buffer(buf)
 
     # ------------------------------------------------------------------------------------------------
+    def _build_hint(self):
+        """This layer's own memory of the graphs it has seen (graph.BuildHint: which CSR build to take); not a parameter, not in
+        the state_dict."""
+        h = self.__dict__.get('_graph_hint')
+        if h is None:
+            h = self.__dict__['_graph_hint'] = BuildHint()
+        return h
+
     fuse_linear = True   # class-level switch: set conv.fuse_linear = False to force the unfused kernels
     cache_graph = False  # set conv.cache_graph = True to reuse the CSR while edge_index is unchanged
 
@@ -564,7 +587,7 @@ class FSW_conv(_Base):
             rel = edge_index[1] - r0
             mine = torch.nonzero((rel >= 0) & (rel < nl)).squeeze(1)                        # one compaction for both endpoints
             sub = edge_index.index_select(1, mine)
-            graph = build_csr(sub[1] - r0, sub[0], None, nl, n, want_invperm=True)          # nl recipient rows, n sender columns
+            graph = build_csr(sub[1] - r0, sub[0], None, nl, n, want_invperm=True, hint=self._build_hint())   # nl recipient rows, n sender columns
             # recipients outside [0, n) belong to no rank's block: flag them like the CSR build flags a bad endpoint (read with
             # the stats in prepare(): "adjacency index out of range", as on one GPU)
             oob = ((edge_index[1] < 0) | (edge_index[1] >= n)).any().to(torch.int32) * _lib.FLAG_INDEX_RANGE
@@ -604,12 +627,14 @@ class FSW_conv(_Base):
         mode    'gather'    all-gather of the embedding blocks (bit-identical to one GPU), the tail replicated;
                 'consumer'  the first Linear layer stays sharded: partial sums reduce-scattered, finished rows all-gathered
                             (needs the fused configuration; raises otherwise);
+                'exchange'  ONE all-to-all hands every row block the slice blocks of all ranks, the owner runs the whole tail on its
+                            rows, one all-gather of the output rows -- the fewest bytes from 4 ranks on (dist.py); any configuration;
                 'auto'      consumer where it applies, else gather.  Training always takes the differentiable gather form.
         chunks  node-range chunks of the pipeline (collective of chunk c under the kernels of chunk c + 1); default by size.
         output  'replicated' (the reference's contract: every rank returns all rows) or, consumer form only, 'sharded':
                 returns (rows [chunks, chunk_rows / world, out], first_row [chunks]) -- this rank's finished rows.
         stats   optional dict that every forward fills with the form taken and the bytes each rank sent."""
-        assert mode in ('auto', 'gather', 'consumer') and output in ('replicated', 'sharded')
+        assert mode in ('auto', 'gather', 'consumer', 'exchange') and output in ('replicated', 'sharded')
         self._slice_parallel = dict(group=group, mode=mode, chunks=chunks, output=output, stats=stats) if enabled else None
         return self
 

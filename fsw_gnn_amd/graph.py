@@ -18,7 +18,7 @@ class CSRGraph:
     """
 
     def __init__(self, num_rows, num_cols, num_edges, rowptr, col, w, perm, bin_start, stats_dev, invperm=None, ef=None,
-                 slot_of_edge=None, chunk_rows=0, meta=None):
+                 slot_of_edge=None, chunk_rows=0, meta=None, hint=None):
         self.num_rows, self.num_cols, self.num_edges = num_rows, num_cols, num_edges
         # chunk_rows > 0: bin_start is [num_chunks, NUM_BINS + 1], rows binned per chunk of chunk_rows consecutive rows
         self.chunk_rows = chunk_rows
@@ -32,6 +32,7 @@ class CSRGraph:
         self._sender_major = None
         self._meta = meta                   # int32 [NUM_STATS + num_chunks * (NUM_BINS + 1)]: stats_dev | bin_start, or None
         self.bin_start_host = None          # numpy int32 [num_chunks, NUM_BINS + 1] after read_stats()
+        self._hint = hint                   # BuildHint of the layer that built the graph (told the maximal degree when it is read)
 
     def sender_major(self):
         """(cptr int32[num_cols + 1], order int32[nnz]): the CSR entries listed sender by sender (fsw_graph_transpose), built on
@@ -60,10 +61,8 @@ class CSRGraph:
             self.bin_start_host = host[_lib.NUM_STATS:].reshape(self.num_chunks, _lib.NUM_BINS + 1)
         else:
             self._stats = self.stats_dev.cpu().tolist()
-        global _last_graph_skewed
-        _last_graph_skewed = self._stats[_lib.STAT_MAX_DEGREE] > TWO_LEVEL_MAX_DEGREE
-        if _last_graph_skewed:
-            _skewed_shapes.add((self.num_rows, self.num_edges))
+        if self._hint is not None:
+            self._hint.note(self.num_rows, self.num_edges, self._stats[_lib.STAT_MAX_DEGREE])
         return self._stats
 
     def stats(self):
@@ -95,18 +94,38 @@ def round_chunk_rows(rows, multiple_of=1):
     return max(1, -(-int(rows) // m)) * m
 
 
-# Shapes (rows, edges) whose last build showed hub rows: the two-level build (one workgroup per bucket of 2048 rows) would
-# serialise on the hubs' buckets, so those shapes go back to the LSD passes.  Both builds give the same CSR, entry for entry.
-_skewed_shapes = set()
-_last_graph_skewed = False          # a stream of different graphs (mini-batches of one dataset) usually shares its character
 TWO_LEVEL_MAX_DEGREE = 2048
 
 
-def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False, chunk_rows=0, algo="auto"):
+class BuildHint:
+    """What ONE owner (an FSW_conv / FSW_embedding instance) has learnt about the graphs it is fed, to pick between the two CSR
+    builds -- which give the same CSR, entry for entry, so the choice only moves time.  The two-level build (one workgroup per
+    bucket of 2048 rows, csrc/graph_build.hip) is the faster one on graphs without hub rows (0.25 against 0.31 ms at BASELINE
+    config 3) but serialises on a hub-heavy bucket (6.4 ms once on the 64M-edge RMAT graph); the degrees are only known after
+    the build.  So: the LSD build until this owner has seen a graph without rows above TWO_LEVEL_MAX_DEGREE neighbours, the
+    two-level build while the last graph it saw -- and the last one of this shape -- had none.  No process-wide state: two layers
+    fed different datasets do not influence each other, and a graph of unknown character never takes the risky build."""
+
+    def __init__(self):
+        self.last_skewed = None             # None: nothing seen yet
+        self.skewed_shapes = set()
+
+    def note(self, num_rows, num_edges, max_degree):
+        self.last_skewed = max_degree > TWO_LEVEL_MAX_DEGREE
+        if self.last_skewed:
+            self.skewed_shapes.add((num_rows, num_edges))
+        else:
+            self.skewed_shapes.discard((num_rows, num_edges))
+
+    def two_level(self, num_rows, num_edges):
+        return self.last_skewed is False and (num_rows, num_edges) not in self.skewed_shapes
+
+
+def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=False, chunk_rows=0, algo="auto", hint=None):
     """recipients/senders: int64 CUDA tensors [E]; edge_w: float32 CUDA tensor [E] or None (unit weights).
     chunk_rows > 0: degree bins per chunk of chunk_rows consecutive rows (include/fsw_hip.h, fsw_graph_build).
-    algo: 'lsd' (fsw_graph_build), 'two_level' (fsw_graph_build_two_level), or 'auto' = two_level unless the last graph of this
-    shape -- or the graph before this one -- had a row above TWO_LEVEL_MAX_DEGREE neighbours (noted when the stats are read)."""
+    algo: 'lsd' (fsw_graph_build), 'two_level' (fsw_graph_build_two_level), or 'auto' = what `hint` (the caller's BuildHint)
+    allows: two_level once the caller has seen graphs without hub rows, the LSD build otherwise and without a hint."""
     L = _lib.lib()
     dev = recipients.device
     if dev.type != "cuda":
@@ -132,14 +151,14 @@ def build_csr(recipients, senders, edge_w, num_rows, num_cols, want_invperm=Fals
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     assert algo in ("auto", "lsd", "two_level")
-    two_level = algo == "two_level" or (algo == "auto" and (num_rows, E) not in _skewed_shapes and not _last_graph_skewed)
+    two_level = algo == "two_level" or (algo == "auto" and hint is not None and hint.two_level(num_rows, E))
     fn = L.fsw_graph_build_two_level if two_level else L.fsw_graph_build
     rc = fn(_lib.ptr(recipients), _lib.ptr(senders), _lib.ptr(edge_w), E, num_rows, num_cols, chunk_rows,
             _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(w), _lib.ptr(perm), _lib.ptr(invperm), _lib.ptr(bin_start),
             _lib.ptr(stats), _lib.ptr(ws), ws_bytes, stream)
     _lib.check(rc, "fsw_graph_build")
     return CSRGraph(num_rows, num_cols, E, rowptr, col, w, perm, bin_start if chunk_rows else bin_start.view(-1), stats, invperm,
-                    chunk_rows=chunk_rows, meta=meta)
+                    chunk_rows=chunk_rows, meta=meta, hint=hint)
 
 
 def build_csr_coalesced(recipients, senders, edge_w, edge_feat, num_rows, num_cols, want_slots=False):

@@ -1306,6 +1306,23 @@ with torch.no_grad():
         raise SystemExit("batch-statistics BatchNorm on a row shard must be refused")
     except NotImplementedError:
         pass
+    # 2c. exchange form: all-to-all of the slice blocks to the row owners, the tail on the owned rows, all-gather of the output
+    for chunks in (1, 2):
+        conv.enable_slice_parallel(None, mode="exchange", chunks=chunks, stats=st)
+        yx = conv(X, ei)
+        assert st["mode"] == "exchange" and st["collective"] == "all_to_all+all_gather", st
+        assert tuple(yx.shape) == tuple(ref_u.shape) and rel(yx, ref_u) < 1e-6, rel(yx, ref_u)   # same embedding bits, GEMM on a row subset
+    conv.enable_slice_parallel(None, mode="exchange", chunks=2, output="sharded", stats=st)
+    Rx, row0x = conv(X, ei)
+    assert st["collective"] == "all_to_all"
+    for c in range(Rx.shape[0]):
+        r0 = int(row0x[c]); r1 = min(r0 + Rx.shape[1], n)
+        if r1 > r0:
+            assert rel(Rx[c, :r1 - r0], ref_u[r0:r1]) < 1e-6
+    conv2.eval()
+    conv2.enable_slice_parallel(None, mode="exchange", chunks=2)
+    assert rel(conv2(X, ei), ref_bn) < 1e-5                        # Linear -> BatchNorm (eval) -> act -> Linear tail on the owned rows
+    conv2.enable_slice_parallel(None, enabled=False)
     # 3. auto on a graph with long rows: the consumer form does not apply, the gather form takes over
     ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
                      torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
@@ -1315,6 +1332,14 @@ with torch.no_grad():
     conv.enable_slice_parallel(None, enabled=False)
     ref2 = conv(X, ei2)
     assert rel(y2, ref2) < 1e-6
+    conv.enable_slice_parallel(None, mode="exchange", stats=st)   # the exchange form covers long rows too
+    y2x = conv(X, ei2)
+    assert st["mode"] == "exchange" and rel(y2x, ref2) < 1e-6
+    convw = FSW_conv(d, 12, embed_dim=31, edge_weighting="gcn", self_loop_weight=0.5, mlp_layers=0, device=dev)   # general weights, dim_reduct tail
+    refw = convw(X, ei)
+    convw.enable_slice_parallel(None, mode="exchange", chunks=2, stats=st)
+    yw = convw(X, ei)
+    assert st["mode"] == "exchange" and rel(yw, refw) < 1e-6, rel(yw, refw)
     conv.enable_slice_parallel(None, mode="auto", stats=st)
     ya = conv(X, ei)
     assert st["mode"] == "consumer" and rel(ya, ref) < 1e-6

@@ -112,7 +112,8 @@ _WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from fsw_gnn_amd.dist import slice_partition, all_gather_slice_blocks, pipelined_gather, reduce_scatter_pipeline
+from fsw_gnn_amd.dist import (slice_partition, all_gather_slice_blocks, pipelined_gather, reduce_scatter_pipeline,
+                              all_to_all_pipeline, interleave_blocks)
 from oracle import fsw_oracle as O
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -181,6 +182,36 @@ for cs in (8 * world, 16 * world, 64 * world):
         assert r0 == c * cs + rank * m
         if r1 > r0:
             assert float(np.abs(R[c, :r1 - r0].numpy() - ref[r0:r1]).max() / np.abs(ref).max()) < 1e-13
+
+# 4. exchange form: all-to-all of the slice blocks to the owners of the rows, the tail on the owned rows, all-gather of the output
+Wt = torch.from_numpy(W)
+def finish_x(c, r0, r1, blocks, Yc):
+    rows = r1 - r0
+    buf = torch.empty((rows, 1 + S + d), dtype=torch.float64)
+    interleave_blocks(blocks[:, :rows], parts, 1, buf)
+    assert float(np.abs(buf[:, :1 + S].numpy() - full[r0:r1]).max()) == 0.0     # the owner holds the single-GPU embedding rows
+    buf[:, 1 + S:] = Xt[r0:r1]
+    Yc[:rows] = torch.nn.functional.leaky_relu(buf @ Wt.t() + bt, 0.2)
+for cs in (8 * world, 16 * world, 64 * world):
+    nch = -(-n // cs)
+    def block(c, lc):
+        r0, r1 = c * cs, min((c + 1) * cs, n)
+        lc[:r1 - r0] = localt[r0:r1]
+    stats = {}
+    Y = all_to_all_pipeline(block, finish_x, nch, cs, n, 1 + wmax, H, torch.float64, torch.device("cpu"), None, "replicated", stats)
+    assert tuple(Y.shape) == (n, H)
+    assert float(np.abs(Y.numpy() - ref).max() / np.abs(ref).max()) < 1e-13
+    assert stats["collective"] == "all_to_all+all_gather"
+    assert stats["bytes_sent_per_rank"] == nch * cs * ((1 + wmax) + H) * 8 * (world - 1) // world
+    R, row0 = all_to_all_pipeline(block, finish_x, nch, cs, n, 1 + wmax, H, torch.float64, torch.device("cpu"), None, "sharded", stats)
+    assert stats["collective"] == "all_to_all"
+    m = cs // world
+    for c in range(nch):
+        r0 = int(row0[c]); r1 = min(r0 + m, n)
+        assert r0 == c * cs + rank * m
+        if r1 > r0:
+            assert float(np.abs(R[c, :r1 - r0].numpy() - ref[r0:r1]).max() / np.abs(ref).max()) < 1e-13
+        assert not R[c, max(r1 - r0, 0):].any()
 dist.barrier()
 if rank == 0:
     print("SHARD_OK")
@@ -189,8 +220,8 @@ if rank == 0:
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_slice_sharding_collective_forms_gloo(world, tmp_path):
-    """dist.py's three ways of reassembling a slice-sharded layer (all-gather, pipelined all-gather, sharded consumer with
-    reduce-scatter), the kernels replaced by the oracle restricted to the rank's slices."""
+    """dist.py's ways of reassembling a slice-sharded layer (all-gather, pipelined all-gather, sharded consumer with
+    reduce-scatter, all-to-all exchange to the row owners), the kernels replaced by the oracle restricted to the rank's slices."""
     golden("tiny_graph")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
@@ -253,9 +284,9 @@ def test_bench_self_launch_command_and_relay(tmp_path, capfd):
     assert cmd == ["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                    "--master-port", "29517", "/x/bench.py"] + argv
     args = bench.parse(argv)
-    assert args.gpus == 8 and args.forms == ["gather", "consumer"] and args.slices == 256
+    assert args.gpus == 8 and args.forms == ["gather", "consumer", "exchange"] and args.slices == 256
     assert bench.parse(["--mode", "consumer", "--output", "sharded"]).forms == ["consumer_sharded"]
-    assert bench.parse(["--no-fuse"]).forms == ["gather"]
+    assert bench.parse(["--no-fuse"]).forms == ["gather", "exchange"]
     assert bench.parse(["--slices", "1024"]).slices == 1024
     # the relay, with a stand-in for the rank program: two ranks, rank 0 prints the line, everybody prints noise
     script = tmp_path / "fake_rank.py"

@@ -27,7 +27,7 @@ with torch.no_grad():
         dist.get_world_size = lambda group=None, w=world: w
         dist.get_rank = lambda group=None: 0
         for output in ("replicated", "sharded"):
-            if args.mode != "consumer" and output == "sharded":
+            if args.mode == "gather" and output == "sharded":
                 continue
             st = {}
             conv.enable_slice_parallel(None, mode=args.mode, chunks=args.chunks or None, output=output, stats=st)
