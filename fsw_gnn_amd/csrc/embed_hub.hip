@@ -218,6 +218,197 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, FSW_HUB_MINWAVES) 
   }
 }
 
+// ---- 2049..32768 neighbours with 16-byte gathers: a workgroup takes FOUR adjacent slices of one row, one after the other ----------
+// The line of slice k0 (a multiple of 4: S % 4 == 0) is gathered as float4 = slices k0 .. k0 + 3; the first component goes into the
+// registers, the other three into the lane's own places of a stash in global memory (lane-contiguous 4-byte stores), from where the
+// SAME lane reads them back (coalesced) when the workgroup turns to slices k0 + 1 .. k0 + 3: no synchronisation, 6 bytes of streamed
+// traffic per key in exchange for a quarter of the scattered requests -- which are what bounds these kernels (gather alone: 0.37 of
+// 0.41 ms / 0.70 of 0.90 / 0.44 of 0.72 on the three populated classes of the RMAT-20 graph, tools/exp_hub.sh).
+// stash: 3 * NW * 64 * M floats per workgroup of the grid.
+template <int NW, int M>
+__global__ void __launch_bounds__(NW* kWave, FSW_HUB_MINWAVES) k_embed_hub_q4(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
+    const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
+    int has_mass, int mass_fn, float mass_scale, int dmin, int dmax, float* __restrict__ stash_all) {
+  static_assert(NW > 1, "one line across several wavefronts");
+  constexpr int CAP = M * kWave;
+  constexpr int G8 = 8;      // stash places per immediate-offset window (8 x 256 bytes)
+  __shared__ float xbuf[NW * CAP];
+  __shared__ float red[NW];
+  const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  // wave-uniform base of the wavefront's part of the stash (scalar registers); element (line, j, lane) at
+  // swave[line * NW * CAP + j * 64 + lane]: the lane is the only vector term of every stash address
+  float* swave = stash_all + (int64_t)blockIdx.x * (3 * NW * CAP) + w * CAP;
+  const int xcd = blockIdx.x & 7;
+  // ONE loop over (slice quad, slice of the quad): step n works on line sl = n & 3 of the workgroup's (n >> 2)-th quad
+  for (int64_t n = 0;; ++n) {
+    const int64_t vb = blockIdx.x + (n >> 2) * (int64_t)gridDim.x;
+    const int sl = (int)(n & 3);
+    const int64_t i = (vb >> 3) * 4;
+    const int64_t rl = i / S;
+    const int k0 = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    if (D < dmin || D > dmax) continue;
+    WaveLine<M, false> ln;
+    if (sl == 0) {
+      const int32_t* colrow = col + start;
+      const float* xr = Xp + k0;
+      // batches of G elements: G column indices, then G 16-byte gathers (4 G registers in flight), stashed before the next batch
+      constexpr int G = 8;
+      static_assert(M % G == 0, "keys per lane: a multiple of 8");
+      int c[2][G];
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        const int t = w * CAP + q * kWave + lane;
+        c[0][q] = colrow[min(t, D - 1)];             // past the end: the last neighbour again (its key is replaced by +inf below)
+      }
+      // three running pointers into the stash (lines k0 + 1 .. k0 + 3), bumped once per batch, immediate offsets inside a batch.
+      // The empty asm statements make them opaque: left alone the compiler forms a 64-bit vector address for every one of the
+      // 3 M stash places, hoists them out of the loop over the lines and spills them (250 registers).
+      float* p0 = swave + lane;
+      float* p1 = p0 + NW * CAP;
+      float* p2 = p1 + NW * CAP;
+      asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+#pragma unroll
+      for (int g = 0; g < M / G; ++g) {
+        if (g + 1 < M / G) {
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            const int t = w * CAP + ((g + 1) * G + q) * kWave + lane;
+            c[(g + 1) & 1][q] = colrow[min(t, D - 1)];
+          }
+        }
+        float4 v[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const int cc = c[g & 1][q];                  // always a valid row: no branch around the load
+          if constexpr (FSW_HUB_ABL & 1) v[q].x = v[q].y = v[q].z = v[q].w = (float)((cc * 2654435761u) >> 8);
+          else v[q] = *reinterpret_cast<const float4*>(xr + (int64_t)cc * ldp);
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          if (w * CAP + (g * G + q) * kWave + lane >= D) v[q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+          ln.k[g * G + q] = v[q].x;
+          p0[q * kWave] = v[q].y;
+          p1[q * kWave] = v[q].z;
+          p2[q * kWave] = v[q].w;
+        }
+        p0 += G * kWave;
+        p1 += G * kWave;
+        p2 += G * kWave;
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));   // also keeps the batches apart (all M gathers at once: 4 M registers)
+      }
+    } else {
+      const float* src = swave + (sl - 1) * NW * CAP + lane;
+      asm volatile("" : "+v"(src));
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        ln.k[j] = src[(j % G8) * kWave];
+        if ((j % G8) == G8 - 1) {
+          src += G8 * kWave;
+          asm volatile("" : "+v"(src));
+        }
+      }
+    }
+    if (!(FSW_HUB_ABL & 2)) ln.sort();
+    workgroup_merge_levels<NW, M>(ln, xbuf, w, lane);
+    float tot = wave_sum_h(unit_readout<M>(ln, w * CAP + lane * M, D, freqs[k0 + sl]));
+    if (lane == 0) red[w] = tot;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) tot += red[q];
+    __syncthreads();
+    if (lane == 0 && w == 0) {
+      const int k = k0 + sl;
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
+// ---- 513..2048 neighbours with 16-byte gathers: the four wavefronts of a workgroup take four ADJACENT slices of one row ----------
+// k_embed_hub<1, M> reads 4 bytes per lane from 64 different rows of Xp per instruction, and that -- the number of requests, not the
+// bytes -- is what bounds it (gather alone 1.18 of the class's 1.73 ms on the RMAT-20 graph, tools/exp_hub.sh).  Here wavefront w
+// gathers a QUARTER of the row's elements as float4 = slices k0 .. k0 + 3 (k0 a multiple of 4: S % 4 == 0) and the four lines are
+// dealt to their wavefronts through LDS: one conflict-free ds_write_b32 and one ds_read_b32 per key, a quarter of the global load
+// instructions with 16 bytes per request.  Sort and readout are those of k_embed_hub<1, M> (one line in the registers of one wavefront).
+template <int M>
+__device__ __forceinline__ float hub_quad_line(const float* __restrict__ xline, int D, float xif, int lane) {
+  WaveLine<M, false> ln;
+#pragma unroll
+  for (int j = 0; j < M; ++j) ln.k[j] = xline[j * kWave + lane];     // striped: any arrangement will do, the line is sorted next
+  if (!(FSW_HUB_ABL & 2)) ln.sort();
+  return wave_sum_h(unit_readout<M>(ln, lane * M, D, xif));
+}
+
+template <int M>
+__global__ void __launch_bounds__(256, FSW_HUB_MINWAVES) k_embed_hub_quad(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
+    const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
+    int has_mass, int mass_fn, float mass_scale, int dmin, int dmax) {
+  constexpr int CAP = M * kWave;
+  constexpr int MS = (M * 3) / 4;
+  __shared__ float xq[4][CAP];
+  const int pbeg = bin_start[bin], nrows = bin_start[bin + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  const int xcd = blockIdx.x & 7;
+  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
+    const int64_t i = (vb >> 3) * 4;              // the workgroup's first line; S % 4 == 0: its four lines are one row's
+    const int64_t rl = i / S;
+    const int k0 = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;                       // the whole workgroup
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    if (D < dmin || D > dmax) continue;
+    const int32_t* colrow = col + start;
+    const float* xr = Xp + k0;
+    const bool small = FSW_HUB_SPLIT && D <= kWave * MS;      // a line of at most 3/4 of the class size: 3/4 of the keys per lane
+    const int nq = small ? MS / 4 : M / 4;
+    static_assert(M % 16 == 0, "3/4 of the keys per lane must still be a multiple of 4");
+    int c[M / 4];
+#pragma unroll
+    for (int q = 0; q < M / 4; ++q) {
+      const int t = (q * 4 + w) * kWave + lane;
+      c[q] = colrow[min(t, D - 1)];                  // past the end: the last neighbour again (replaced by +inf below)
+    }
+#pragma unroll
+    for (int q = 0; q < M / 4; ++q) {
+      if (q < nq) {                                 // wave-uniform
+        const int t = (q * 4 + w) * kWave + lane;
+        float4 v;
+        if constexpr (FSW_HUB_ABL & 1) v.x = v.y = v.z = v.w = (float)((c[q] * 2654435761u) >> 8);
+        else v = *reinterpret_cast<const float4*>(xr + (int64_t)c[q] * ldp);
+        if (t >= D) v = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+        xq[0][t] = v.x;
+        xq[1][t] = v.y;
+        xq[2][t] = v.z;
+        xq[3][t] = v.w;
+      }
+    }
+    __syncthreads();
+    const float xif = freqs[k0 + w];
+    const float tot = small ? hub_quad_line<MS>(xq[w], D, xif, lane) : hub_quad_line<M>(xq[w], D, xif, lane);
+    __syncthreads();                               // every line has been read: the next row may overwrite the buffer
+    if (lane == 0) {
+      const int k = k0 + w;
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
 // ---- rows above FSW_HUB_MAX_DEG, unit weights: blocks of 16384 keys sorted in the registers of an 8-wavefront workgroup --
 // A line (row, slice) of any length is cut into blocks of kGiantBlk = 8 * 2048 keys (8 wavefronts: 16 would leave 128 registers per lane and spill).  Every block is gathered and sorted
 // like a hub row and parked in the workgroup's scratch line (global memory, 4 bytes per key); the bitonic merge levels
@@ -371,6 +562,31 @@ static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipS
   // (a dispatch holds < 2^32 work-items: 17.7M x 256 threads were silently truncated on a 64M-edge graph) and strides
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
+  if constexpr (NW == 1 && M % 16 == 0) {
+    // 16-byte gathers dealt through LDS when the workgroup's four lines are four slices of one row (k_embed_hub_quad)
+    if (a.S % 4 == 0 && a.ldp % 4 == 0 && ((uintptr_t)a.Xp & 15) == 0) {
+      k_embed_hub_quad<M><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                                 a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, dmin, dmax);
+      FSW_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  if constexpr (NW > 1) {
+    // 16-byte gathers with the other three slices stashed in the caller's scratch buffer (k_embed_hub_q4): the grid is bounded by
+    // the stash (3 * NW * 64 * M floats per workgroup) and by what is resident anyway (the workgroups stride over the lines)
+    const size_t per_wg = (size_t)3 * NW * kWave * M * sizeof(float);
+    if (a.S % 4 == 0 && a.ldp % 4 == 0 && ((uintptr_t)a.Xp & 15) == 0 && a.scratch && ((uintptr_t)a.scratch & 15) == 0 &&
+        a.scratch_bytes >= 8 * per_wg) {
+      int64_t nq = ceil_div(ceil_div(rows_upper, 8) * (a.S / 4), 1) * 8;                 // virtual blocks: 8 rows x S / 4 slice quads
+      nq = std::min<int64_t>(nq, std::min<int64_t>((int64_t)(a.scratch_bytes / per_wg), 256 * 16 / NW));
+      nq &= ~(int64_t)7;
+      k_embed_hub_q4<NW, M><<<(unsigned)nq, NW * kWave, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs,
+                                                                   a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
+                                                                   dmin, dmax, reinterpret_cast<float*>(a.scratch));
+      FSW_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   k_embed_hub<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, 0, stream>>>(
       a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
       a.mass_scale, dmin, dmax);
@@ -398,7 +614,32 @@ static int launch_hub_pair(const fsw_embed_args& a, int bin, int64_t rows_upper,
 //                      lane's registers (embed_mid.hip: 160..256 keys -> one wave per SIMD, which can issue a vector instruction
 //                      only every 4 cycles and has nothing to overlap its gather with); split over four lanes the line takes
 //                      48..64 registers per lane and 3..4 waves per SIMD cover each other's gathers.
-template <int M, int LL>   // line = LL * M keys
+// 4 x 4 transpose across the four rows of 16 lanes: lane (s, j) holds v[c] = slice c of ITS element and receives v[c] = slice s of
+// the element of lane (c, j).  Two v_permlane32_swap (rows {0,1} <-> {2,3}) and two v_permlane16_swap (even <-> odd rows): one
+// instruction per key, no LDS crossbar.
+__device__ __forceinline__ void transpose_rows_4x4(float (&v)[4]) {
+  auto swap32 = [](float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+  };
+  auto swap16 = [](float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+  };
+  swap32(v[0], v[2]);
+  swap32(v[1], v[3]);
+  swap16(v[0], v[1]);
+  swap16(v[2], v[3]);
+}
+
+// VEC4 (LL = 16, S % 4 == 0): the wavefront's four lines are slices k0 .. k0 + 3 of ONE row, k0 a multiple of 4.  Lane (s, j) then
+// loads 16 bytes -- the four slices of its neighbour -- for a quarter of the line's elements and the values are dealt to the four
+// lines in registers (transpose_rows_4x4).  A quarter of the load instructions, each request 16 bytes instead of 4: the 4-byte
+// gathers of the long-row kernels are bound by the number of requests, not by bytes (gather alone: 531 G keys/s here, 322 G keys/s
+// in the 64-lane lines of k_embed_hub, whatever the sort costs -- tools/exp_hub.sh).
+template <int M, int LL, bool VEC4 = false>   // line = LL * M keys
 __global__ void __launch_bounds__(256, M <= 32 ? 4 : M <= 64 ? 3 : 2) k_embed_rowlines(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start, int bin,
                                                            const float* __restrict__ Xp, int64_t ldp, int S, const float* __restrict__ freqs,
@@ -422,6 +663,31 @@ __global__ void __launch_bounds__(256, M <= 32 ? 4 : M <= 64 ? 3 : 2) k_embed_ro
     WaveLine<M, false, false, LL> ln;
     const int32_t* colrow = col + start;
     const float* xk = Xp + k;
+    if constexpr (VEC4) {
+      static_assert(LL == 16 && M % 4 == 0, "four lines of 16 lanes");
+      const int sline = lane >> 4;
+      const float* xq = Xp + (k - sline);           // slice k0 of the row: 16-byte aligned
+      int c[M / 4];
+#pragma unroll
+      for (int i = 0; i < M / 4; ++i) {
+        const int t = (i * 4 + sline) * LL + sub;
+        c[i] = colrow[min(t, D - 1)];                // past the end: the last neighbour again (replaced by +inf below)
+      }
+#pragma unroll
+      for (int i = 0; i < M / 4; ++i) {
+        float v[4];
+        if constexpr (FSW_HUB_ABL & 1) {
+          v[0] = v[1] = v[2] = v[3] = (float)((c[i] * 2654435761u) >> 8);
+        } else {
+          const float4 q = *reinterpret_cast<const float4*>(xq + (int64_t)c[i] * ldp);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+        if ((i * 4 + sline) * LL + sub >= D) v[0] = v[1] = v[2] = v[3] = __builtin_inff();
+        transpose_rows_4x4(v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ln.k[i * 4 + u] = v[u];
+      }
+    } else {
     // striped element order (lane-contiguous col reads; the line is sorted next).  Column indices one batch ahead of their gathers.
     constexpr int G = M % 16 == 0 ? 16 : 8;
     static_assert(M % G == 0, "keys per lane: a multiple of 8");
@@ -446,6 +712,7 @@ __global__ void __launch_bounds__(256, M <= 32 ? 4 : M <= 64 ? 3 : 2) k_embed_ro
         ln.k[g * G + q] = cc >= 0 ? ((FSW_HUB_ABL & 1) ? (float)((cc * 2654435761u) >> 8) : xk[(int64_t)cc * ldp]) : __builtin_inff();
       }
     }
+    }
     if (!(FSW_HUB_ABL & 2)) ln.sort();
     float tot = unit_readout<M>(ln, sub * M, D, freqs[k]);
     if constexpr (LL >= 16) tot += xor_lane<8>(tot);
@@ -467,6 +734,17 @@ static int launch_rowlines_one(const fsw_embed_args& a, int bin, int64_t rows_up
   if (rows_upper <= 0) return 0;
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
+  // 16-byte gathers: the four lines of a wavefront must be four slices of one row starting at a multiple of 4
+  const bool vec4 = LL == 16 && a.S % 4 == 0 && a.ldp % 4 == 0 && ((uintptr_t)a.Xp & 15) == 0;
+  if constexpr (LL == 16) {
+    if (vec4) {
+      k_embed_rowlines<M, LL, true><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S,
+                                                                          a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
+                                                                          a.mass_scale, dmin, dmax);
+      FSW_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   k_embed_rowlines<M, LL><<<(unsigned)nblocks, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin, a.Xp, a.ldp, a.S, a.freqs, a.out,
                                                                 a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, dmin, dmax);
   FSW_LAUNCH_CHECK();

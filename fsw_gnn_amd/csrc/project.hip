@@ -273,7 +273,10 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
                                                      const float* __restrict__ W2, int H2, int64_t ldw2,
                                                      const float* __restrict__ b2, float* __restrict__ Y2, int64_t ldy2,
                                                      const int32_t* __restrict__ row_map, int64_t ntiles, int nslab_waves,
-                                                     int nsl1, int y2_vec) {
+                                                     int nsl1, int y2_vec, int cbufs) {
+  // cbufs: buffers of the C staging tile.  2: one barrier per tile orders everything; 1: a second barrier per tile, half the
+  // staging LDS -- with the slabs split over two column groups (6 slab waves each) two workgroups then share a CU and cover
+  // each other's load / matrix / store phases.
   // KS <= 8 (d <= 128): up to 12 slab waves keep their whole slab of [V; W2] in registers (24 KS registers each).
   // KS == 16 (d <= 256): the slab takes 192 registers, so a workgroup is 4 slab waves + 4 waves that only move X, two waves
   // per SIMD at up to 256 registers, and the column groups beyond the first re-read X (from L2 / the Infinity Cache mostly).
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   APlanes As = reinterpret_cast<APlanes>(smem);
   const int ldc = nslab_waves * 32 + 4;
   float* Cs = reinterpret_cast<float*>(smem + sizeof(__bf16) * 2 * 3 * BS_ROWS * B3_LD);
-  int* rmap = reinterpret_cast<int*>(Cs + 2 * BS_ROWS * ldc);
+  int* rmap = reinterpret_cast<int*>(Cs + cbufs * BS_ROWS * ldc);
 
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   const int w2 = (nslab_waves - max(g1, 0)) * 8;                           // float4 per staged row, second block
   const int col1 = blockIdx.y * nslab_waves * 32;                          // first Xp column of this group
   const int col2 = max((int)blockIdx.y * nslab_waves - nsl1, 0) * 32;      // first Y2 column of this group
-  auto write_out = [&](int cb, int64_t tile) {
+  auto write_out = [&](int cb, int64_t tile, int rb) {
     const int64_t row0 = tile * BS_ROWS;
     const float* cs = Cs + cb * BS_ROWS * ldc;
     for (int i = threadIdx.x; i < BS_ROWS * w1; i += blockDim.x) {
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
       if (row0 + r >= n) continue;
       const int cc = col2 + 4 * c4;
       const float4 v = *reinterpret_cast<const float4*>(cs + r * ldc + max(g1, 0) * 32 + 4 * c4);
-      float* yrow = Y2 + (int64_t)rmap[cb * BS_ROWS + r] * ldy2;
+      float* yrow = Y2 + (int64_t)rmap[rb * BS_ROWS + r] * ldy2;
       if (y2_vec && cc + 3 < H2) {
         *reinterpret_cast<float4*>(yrow + cc) = v;
       } else {
@@ -443,22 +446,25 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
         }
       }
 #else
-      float* cs = Cs + buf * BS_ROWS * ldc + wv * 32 + fr;
+      if (cbufs == 1) __syncthreads();   // uniform: the previous tile has left the single staging buffer
+      float* cs = Cs + (cbufs == 2 ? buf : 0) * BS_ROWS * ldc + wv * 32 + fr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
 #endif
+    } else if (cbufs == 1) {
+      __syncthreads();                   // helper waves (no slab) join the same barrier
     }
     __syncthreads();
 #if !FSW_PROJECT_DIRECT_C
-    if (!(FSW_PROJECT_ABL & 2)) write_out(buf, tile);
+    if (!(FSW_PROJECT_ABL & 2)) write_out(cbufs == 2 ? buf : 0, tile, buf);
 #endif
     buf ^= 1;
   }
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
 }
 
-static size_t bf3_lds_bytes(int nwaves, int ks) {
-  return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * 2 * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
+static size_t bf3_lds_bytes(int nwaves, int ks, int cbufs) {
+  return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * cbufs * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
 }
 
 }  // namespace fsw
@@ -482,12 +488,17 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
     const bool exact = d <= 128 && getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
     const int nsl1 = (int)ceil_div(S, 32), nsl2 = (int)ceil_div(H2, 32);
     const int nslabs = exact ? (int)ceil_div(S + H2, 32) : nsl1 + nsl2;
-    const int max_slab_waves = d <= 128 ? 12 : 4;
+    // FSW_PROJECT_GROUPS=2 (experiment): d <= 128 with the slabs in two column groups of <= 6 waves, single C staging buffer, two
+    // workgroups per CU
+    static const int split_groups = [] { const char* e = getenv("FSW_PROJECT_GROUPS"); return e ? atoi(e) : 1; }();
+    const bool split = split_groups == 2 && d <= 128 && !exact;
+    const int max_slab_waves = d <= 128 ? (split ? 6 : 12) : 4;
     const int ngroups = (int)ceil_div(nslabs, max_slab_waves);
     const int nwaves = (int)ceil_div(nslabs, ngroups);
     const int64_t ntiles = ceil_div(n, BS_ROWS);
     dim3 grid((unsigned)std::min<int64_t>(ntiles, 256), (unsigned)ngroups);
-    const int threads = std::max(nwaves, 8) * 64;
+    const int threads = std::max(nwaves, split ? 6 : 8) * 64;
+    const int cbufs = split ? 1 : 2;
     if (exact) {
       // FSW_PROJECT_EXACT_FP32=1: exact-fp32 MFMA kernel instead of bf16x3 (same accuracy class, 2.7x the matrix cycles)
 #define FSW_LAUNCH_BS(KQ)                                                                                                   \
@@ -502,13 +513,13 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
                   "fsw_project: Xp must be 16-byte aligned with ldp >= 32*ceil(S/32), ldp %% 4 == 0");
       const int y2_vec = (H2 > 0 && ldy2 % 4 == 0 && (uintptr_t)Y2 % 16 == 0) ? 1 : 0;
       const int ks = d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16;
-      const size_t lds = bf3_lds_bytes(nwaves, ks);
+      const size_t lds = bf3_lds_bytes(nwaves, ks, cbufs);
 #define FSW_LAUNCH_BF3(KS)                                                                                                  \
   do {                                                                                                                      \
     FSW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_project_bf3<KS>),                                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                               \
     k_project_bf3<KS><<<grid, threads, lds, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, x_copy, ld_copy, W2, H2, ldw2, \
-                                                      b2, Y2, ldy2, row_map, ntiles, nwaves, nsl1, y2_vec);                 \
+                                                      b2, Y2, ldy2, row_map, ntiles, nwaves, nsl1, y2_vec, cbufs);          \
   } while (0)
       if (ks == 2) FSW_LAUNCH_BF3(2);
       else if (ks == 4) FSW_LAUNCH_BF3(4);

@@ -341,14 +341,18 @@ def test_mid_degree_rows_every_padded_network_size(dev):
         assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
 
 
-def test_wave_sort_rows_every_size_class(dev):
-    """Rows of 257..2048 neighbours at both ends of the three wave-sort classes (csrc/embed_wsort.hip: a wave holds a
-    slice's line in registers, 8 / 16 / 32 keys per lane), unit and general weights (one size class up for the pad
-    element; row 0 is mass-deficient), S not a multiple of the slice-group size, a zero frequency."""
+@pytest.mark.parametrize("S", [277, 280])
+def test_wave_sort_rows_every_size_class(dev, S):
+    """Rows of 257..2048 neighbours at both ends of the three wave-sort classes (csrc/embed_hub.hip: k_embed_rowlines -- four lines
+    of 16 lanes x 32 keys per wavefront -- and k_embed_hub<1, M> / k_embed_hub_quad<M> -- a wavefront holds a slice's line in
+    registers, 16 / 32 keys per lane), unit and general weights (the general-weight kernels run one size class up for the pad
+    element; row 0 is mass-deficient), a zero frequency.  S = 277: not a multiple of the slice-group size, 4-byte gathers; S = 280:
+    a multiple of 4, so the unit-weight kernels gather 16 bytes per lane (four slices) and deal the lines out in registers
+    (v_permlane swaps) / through LDS."""
     from fsw_gnn_amd import build_csr, _lib
     rng = np.random.default_rng(23)
-    sizes = [257, 512, 513, 1024, 1025, 2048, 600]
-    nrows, n, d, S = len(sizes), 2300, 8, 277                    # > 256 slices: several chunk groups on every path
+    sizes = [257, 512, 513, 1024, 1025, 2048, 600, 300, 384, 385, 700, 768, 769, 1500, 1536, 1537]
+    nrows, n, d = len(sizes), 2300, 8                            # > 256 slices: several chunk groups on every path
     X = rng.standard_normal((n, d)).astype(np.float32)
     V = cases.synth.unit_slices(S, d, seed=89)
     fr = cases.random_freqs(S, seed=90)
@@ -365,22 +369,24 @@ def test_wave_sort_rows_every_size_class(dev):
             out = torch.empty((nrows, S + 1), device=dev)
             E.embed_into(t(X, dev), graph, out)
         bs = np.diff(graph.bin_start.cpu().numpy())
-        assert bs[-8:].tolist() == [2, 3, 2, 0, 0, 0, 0, 0] and bs[:-8].sum() == 0
+        assert bs[-8:].tolist() == [5, 6, 5, 0, 0, 0, 0, 0] and bs[:-8].sum() == 0
         ref = O.fsw_embedding_forward(X, rowptr, snd, np.ones(rec.size) if weights is None else weights.astype(np.float64), V, fr,
                                       encode_total_mass=True)
         assert relerr(out.cpu().numpy(), ref) < TOL
         assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
 
 
-def test_hub_rows_every_size_class(dev):
+@pytest.mark.parametrize("S", [11, 12])
+def test_hub_rows_every_size_class(dev, S):
     """Rows of 2049..33000 neighbours at both ends of the four hub classes (csrc/embed_hub.hip: a workgroup of 2 / 4 / 8 / 16
     wavefronts holds one slice's line, 2048 keys per wavefront, merge levels above a wavefront through LDS) and one row above
-    them (global-scratch path); unit weights take the hub kernels, general weights the scratch path; a zero frequency;
-    several rows per class so that the XCD-interleaved block order is exercised."""
+    them (k_embed_giant: blocks of 32768 keys); unit weights take the hub kernels, general weights k_embed_hub_w up to 4096
+    neighbours and the scratch-line kernel above; a zero frequency; several rows per class so that the XCD-interleaved block order
+    is exercised.  S = 11: 4-byte gathers; S = 12 (a multiple of 4): the 16-byte gather forms."""
     from fsw_gnn_amd import build_csr, _lib
     rng = np.random.default_rng(29)
     sizes = [2049, 4096, 4097, 8192, 8193, 16384, 16385, 32768, 33000, 3000, 5000, 6000, 7000, 4100, 9000, 9001, 9002, 2500]
-    nrows, n, d, S = len(sizes), 40_000, 6, 11
+    nrows, n, d = len(sizes), 40_000, 6
     X = rng.standard_normal((n, d)).astype(np.float32)
     V = cases.synth.unit_slices(S, d, seed=87)
     fr = cases.random_freqs(S, seed=88)
