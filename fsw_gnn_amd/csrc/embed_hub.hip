@@ -571,7 +571,10 @@ static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipS
       return 0;
     }
   }
-  if constexpr (NW > 1) {
+  if constexpr (NW == 2) {
+    // 2049..4096 neighbours only: measured on the RMAT graphs 0.41 -> 0.36 ms (scale 20) for two wavefronts per line, but 10.2 -> 12.8 ms
+    // (scale 22, 4097..8192) and no change (8193..16384) for four and eight -- there the barrier-separated exchanges between the
+    // wavefronts bound the kernel, not the gather, and the stash traffic is pure cost.
     // 16-byte gathers with the other three slices stashed in the caller's scratch buffer (k_embed_hub_q4): the grid is bounded by
     // the stash (3 * NW * 64 * M floats per workgroup) and by what is resident anyway (the workgroups stride over the lines)
     const size_t per_wg = (size_t)3 * NW * kWave * M * sizeof(float);
@@ -759,6 +762,112 @@ static int launch_rowlines(const fsw_embed_args& a, int bin, int64_t rows_upper,
   int rc;
   if (kSplit && (rc = launch_rowlines_one<24, 16>(a, bin, rows_upper, stream, 0, kSmall))) return rc;
   return launch_rowlines_one<32, 16>(a, bin, rows_upper, stream, kSplit ? kSmall + 1 : 0, 0x7fffffff);
+}
+
+// ---- 129..256 neighbours, whole-row gathers through LDS ------------------------------------------------------------------------------
+// A workgroup of four wavefronts takes (row, chunk of 64 slices).  The neighbours' 256-byte runs Xp[col, k0 .. k0 + 63] -- the
+// access shape that reads HBM best -- go STRAIGHT into LDS (global_load_lds_dword: no register destination, row t of the tile =
+// neighbour t, 64 slices), and they are issued for the NEXT row of the workgroup before the current row is sorted, so the gather runs
+// under the sort.  The 64 lines of the tile are then read transposed, 4 lanes x DP / 4 keys per line (WaveLine<DP / 4, .., 4>: every
+// exchange of the merge levels a DPP move), 16 lines per wavefront; row stride 72 floats makes both the DMA writes (64 consecutive
+// floats) and the transposed reads (bank = 8 sub + line) conflict-free.  Against one lane per slice with the whole row in its
+// registers (embed_mid.hip: one or two waves per SIMD, nothing to overlap the gather with) the line takes a quarter of the registers.
+constexpr int kMidLdsStride = 72;
+
+template <int DP>   // padded line: 192 or 256 keys
+__global__ void __launch_bounds__(256, 2) k_embed_mid_lds(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start, int bin,
+                                                          const float* __restrict__ Xp, int64_t ldp, int S, const float* __restrict__ freqs,
+                                                          float* __restrict__ out, int64_t ldo, const float* __restrict__ bias,
+                                                          float out_scale, int has_mass, int mass_fn, float mass_scale) {
+  constexpr int M = DP / 4, LL = 4;
+  __shared__ float xs[DP * kMidLdsStride];
+  const int lane = lane_id(), w = wave_id();
+  const int sub = lane & (LL - 1), line = lane >> 2;
+  const int k0 = blockIdx.y * kWave;                       // first slice of the chunk
+  const int kl = min(k0 + lane, S - 1);                    // the slice this lane GATHERS (past the end: slice S - 1 again)
+  const int ks = min(k0 + w * 16 + line, S - 1);           // the slice this lane SORTS
+  const bool ks_ok = k0 + w * 16 + line < S;
+  const float xif = freqs[ks];
+  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  // this wavefront gathers neighbours t = w, w + 4, ...: lane i holds the column index of its i-th neighbour (one load per row)
+  auto load_cols = [&](int p, int& D) {
+    int c = 0;
+    D = 0;
+    if (p < pend) {
+      const int node = perm[p];
+      const int start = rowptr[node];
+      D = rowptr[node + 1] - start;
+      const int t = w + 4 * lane;
+      c = col[start + min(t, D - 1)];
+    }
+    return c;
+  };
+  auto issue_gather = [&](int c, int D) {                  // D wave-uniform; neighbours past the end are not loaded (masked at the read)
+    const int mine = (D - w + 3) >> 2;                     // this wavefront's neighbours
+#pragma unroll 8
+    for (int i = 0; i < DP / 4; ++i) {
+      if (i < mine) {                                      // uniform
+        const int ci = __builtin_amdgcn_readlane(c, i);
+        const float* src = Xp + (int64_t)ci * ldp + kl;
+        __builtin_amdgcn_global_load_lds(src, xs + (w + 4 * i) * kMidLdsStride, 4, 0, 0);
+      }
+    }
+  };
+  int p = pbeg + blockIdx.x;
+  int Dn;
+  int cn = load_cols(p, Dn);
+  if (p < pend) issue_gather(cn, Dn);
+  int D = Dn;
+  int node = p < pend ? perm[p] : 0;
+  cn = load_cols(p + gridDim.x, Dn);
+  for (; p < pend; p += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wavefront's DMAs of row p (and the column indices of the next row)
+    __syncthreads();                                       // ... and everybody else's
+    WaveLine<M, false, false, LL> ln;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const int t = i * LL + sub;
+      const float v = xs[t * kMidLdsStride + w * 16 + line];
+      ln.k[i] = t < D ? v : __builtin_inff();
+    }
+    __syncthreads();                                       // the tile has been read: the next row may land in it
+    const int pn = p + gridDim.x;
+    const int Dcur = D, nodecur = node;
+    if (pn < pend) {
+      issue_gather(cn, Dn);
+      D = Dn;
+      node = perm[pn];
+    }
+    cn = load_cols(pn + gridDim.x, Dn);
+    ln.sort();
+    float tot = unit_readout<M>(ln, sub * M, Dcur, xif);
+    tot += xor_lane<2>(tot);
+    tot += xor_lane<1>(tot);
+    if (sub == 0 && ks_ok) {
+      float* orow = out + (int64_t)nodecur * ldo;
+      orow[has_mass + ks] = out_scale * (tot + (bias ? bias[has_mass + ks] : 0.f));
+      if (has_mass && ks == 0) orow[0] = out_scale * (mass_encode_h((float)Dcur, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+  }
+}
+
+int launch_embed_mid_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
+  for (int i = 0; i < FSW_NUM_MID_BINS; ++i) {
+    if (sizes[i] <= 128) continue;
+    const int64_t rows = bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, rows_upper);
+    if (rows <= 0) continue;
+    dim3 grid((unsigned)std::min<int64_t>(rows, 256), (unsigned)ceil_div(a.S, kWave));
+    if (sizes[i] <= 192)
+      k_embed_mid_lds<192><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                     a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+    else
+      k_embed_mid_lds<256><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S, a.freqs, a.out,
+                                                     a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+    FSW_LAUNCH_CHECK();
+  }
+  return 0;
 }
 
 // unit weights, mid bins of 129..256 neighbours (FSW_MID_SIZES 160 / 192 / 256): lines of 192 and 256 keys over LL lanes

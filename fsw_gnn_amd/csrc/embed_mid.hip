@@ -167,6 +167,7 @@ int launch_mid_unit_small(const fsw_embed_args& a, dim3 grid, hipStream_t stream
 int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
 int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream);
 int launch_embed_mid_split(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);   // embed_hub.hip
+int launch_embed_mid_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);     // embed_hub.hip
 
 #define FSW_MID_UNIT(i, DP)                                                                                               \
   if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0)                                                            \
@@ -200,7 +201,8 @@ int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
     // k_embed_rowlines<M, 4>, three waves per SIMD).  Measured SLOWER on the populated bin of the RMAT graphs (129..160 neighbours:
     // 373 against 524 G keys/s; LL = 2 / 8: 379 / 392): four 64-byte pieces per gather instruction instead of one 256-byte run
     // cost more than the occupancy gains -- kept for comparison (tools/exp_skew.py --fine)
-    static const bool split = [] { const char* e = getenv("FSW_MID_SPLIT"); return e && e[0] == '1'; }();
+    static const int split = [] { const char* e = getenv("FSW_MID_SPLIT"); return e ? atoi(e) : 0; }();
+    if (split == 2) return launch_embed_mid_lds(a, rows_upper, stream);   // whole-row gathers through LDS (k_embed_mid_lds)
     return split ? launch_embed_mid_split(a, rows_upper, stream) : launch_mid_unit_large(a, grid, stream);
   }
   return launch_mid_weighted(a, grid, stream);   // bins above FSW_MID_MAX_DEG_WEIGHTED go to the wave-sort path (embed_wsort.hip)

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   // KS == 16 (d <= 256): the slab takes 192 registers, so a workgroup is 4 slab waves + 4 waves that only move X, two waves
   // per SIMD at up to 256 registers, and the column groups beyond the first re-read X (from L2 / the Infinity Cache mostly).
   constexpr int B3_LD = 16 * KS + 8;
-  constexpr int NQ = KS <= 8 ? 2 : 4;     // float4 of an X tile per thread (32 rows x 4 KS float4 over >= 512 threads)
+  constexpr int NQ = KS <= 8 ? 3 : 4;     // float4 of an X tile per thread (32 rows x 4 KS float4 over >= 384 (d <= 128) / 512 threads)
   // LDS: A planes [2][3][32][B3_LD] bf16 | C staging [2][32][ldc] float | row map [2][32] int
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 (*APlanes)[3][BS_ROWS][B3_LD];

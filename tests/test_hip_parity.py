@@ -1080,6 +1080,10 @@ def test_backward_conv10k_training_step(dev):
     assert relerr(gfr, gg["gfreqs"]) < 5e-5
     per_slice = np.array([relerr(gV[k], gg["gV"][k]) for k in range(gV.shape[0])])
     assert np.median(per_slice) < 1e-5 and (per_slice > 1e-4).sum() <= 8 and relerr(gV, gg["gV"]) < 1e-2
+    # ... and the allowance is CONFINED to the slices that hold such a pair: over all other slices together the gradient matches the
+    # reference's norm-wise at the forward's own tolerance
+    clean = per_slice <= 1e-4
+    assert clean.sum() >= gV.shape[0] - 8 and relerr(gV[clean], gg["gV"][clean]) < 5e-5, relerr(gV[clean], gg["gV"][clean])
     assert relerr(X.grad[t(gg["rows"], dev, torch.int64)].cpu().numpy(), gg["gX_rows"]) < 1e-2
     # (2) against the oracle's analytic backward evaluated with the SAME float32 sort order: tight everywhere
     rowptr, col, w, _ = O.coalesce_edge_index(c["edge_index"], c["n"])
