@@ -65,6 +65,8 @@ _SIGNATURES = {
     "fsw_graph_build": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_graph_build_two_level": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "fsw_project_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "fsw_gemm_tn_workspace_bytes": (c_sz, [ctypes.c_int, ctypes.c_int]),
+    "fsw_gemm_tn_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_f32, c_vp, c_sz, c_vp]),
     "fsw_unit_table_rows": (c_sz, [ctypes.c_int]),
     "fsw_unit_coeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_embed_scratch_bytes": (c_sz, [c_i64]),

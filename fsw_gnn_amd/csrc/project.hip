@@ -489,7 +489,7 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
     const int nsl1 = (int)ceil_div(S, 32), nsl2 = (int)ceil_div(H2, 32);
     const int nslabs = exact ? (int)ceil_div(S + H2, 32) : nsl1 + nsl2;
     // FSW_PROJECT_GROUPS=2 (experiment): d <= 128 with the slabs in two column groups of <= 6 waves, single C staging buffer, two
-    // workgroups per CU
+    // workgroups per CU.  Measured SLOWER at config 3 (0.99 against 0.67 ms: X is read twice and every tile pays a second barrier)
     static const int split_groups = [] { const char* e = getenv("FSW_PROJECT_GROUPS"); return e ? atoi(e) : 1; }();
     const bool split = split_groups == 2 && d <= 128 && !exact;
     const int max_slab_waves = d <= 128 ? (split ? 6 : 12) : 4;

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .coherence import minimize_mutual_coherence
-from .fsw_embedding import FSW_embedding
+from .fsw_embedding import FSW_embedding, LinearTallFn, GEMM_TN_MIN_ROWS
 from .graph import BuildHint, build_csr, build_csr_coalesced
 
 try:  # optional dependency, exactly the names the reference imports (fsw_conv.py:4-9)
@@ -337,6 +337,13 @@ class FSW_conv(_Base):
     def _tail(self, emb, vertex_features):
         """concat with the vertex features, MLP / dim_reduct, final BatchNorm through torch autograd (fsw_conv.py:357-369)."""
         h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
+        if (self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear) and h.is_cuda and h.dtype == torch.float32
+                and h.shape[0] >= GEMM_TN_MIN_ROWS and self.mlp[0].weight.requires_grad and torch.is_grad_enabled()):
+            # the first Linear layer with its weight gradient on csrc/gemm_tn.hip (a reduction over the rows), the rest as it is
+            out = LinearTallFn.apply(h, self.mlp[0].weight, self.mlp[0].bias)
+            for m in self.mlp[1:]:
+                out = m(out)
+            return self.bn_final(out) if self.bn_final is not None else out
         out = self.mlp(h) if self.mlp is not None else (torch.matmul(h, self.dim_reduct.transpose(0, 1)) if self.concat_self else h)
         return self.bn_final(out) if self.bn_final is not None else out
 

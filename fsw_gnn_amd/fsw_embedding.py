@@ -20,6 +20,8 @@ import numbers
 import struct
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd.function import once_differentiable
@@ -58,6 +60,48 @@ def _grad_x(L, gXp, S, ldp, V, stream):
                    "fsw_project_f32")
         return out if ldo == d_in else out[:, :d_in].contiguous()
     return gXp[:, :S] @ V
+
+
+GEMM_TN_MIN_ROWS = 1 << 16   # below this the BLAS GEMM is as good
+
+
+def gemm_tn(A, B):
+    """A^T . B for tall row-major A [K, M], B [K, N] (float32, unit inner stride): csrc/gemm_tn.hip when the result fits its 16 blocks
+    of 64 x 64 and K is large (the weight-gradient shape: 1M rows x 256 x 128), the BLAS GEMM otherwise."""
+    K, M = A.shape
+    N = B.shape[1]
+    blocks = -(-M // 64) * -(-N // 64)
+    if (A.is_cuda and K >= GEMM_TN_MIN_ROWS and blocks <= 16 and not os.environ.get("FSW_GEMM_TN_OFF") and A.dtype == torch.float32 and B.dtype == torch.float32
+            and A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == K):
+        L = _lib.lib()
+        C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        wsb = int(L.fsw_gemm_tn_workspace_bytes(M, N))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=A.device)
+        _lib.check(L.fsw_gemm_tn_f32(_lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), K, M, N, _lib.ptr(C), N, 0.0, _lib.ptr(ws), wsb,
+                                     torch.cuda.current_stream(A.device).cuda_stream), "fsw_gemm_tn_f32")
+        return C
+    return A.t() @ B
+
+
+class LinearTallFn(torch.autograd.Function):
+    """y = h . W^T + b like torch.nn.functional.linear, with the weight gradient gW = gy^T . h -- a reduction over the ROWS, a million
+    of them in a training step at BASELINE config 3 -- on gemm_tn instead of the BLAS library's split-K (reference fsw_conv.py:361:
+    the first Linear layer of the MLP applied to cat((emb, vertex_features)))."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        ctx.save_for_backward(h, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, h, W.t()) if b is not None else h @ W.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, W = ctx.saved_tensors
+        gy = gy.contiguous()
+        gh = gy @ W if ctx.needs_input_grad[0] else None
+        gW = gemm_tn(gy, h) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gh, gW, gb
 
 
 class _EmbedGraphFn(torch.autograd.Function):
@@ -164,7 +208,7 @@ class _EmbedGraphFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gX = _grad_x(L, gXp, S, ldp, V[:, :module.d_in], stream)
             if ctx.needs_input_grad[1]:
-                gVb = gXp[:, :S].t() @ X.detach()
+                gVb = gemm_tn(gXp[:, :S], X.detach())
             if ctx.needs_input_grad[2]:
                 gfb = gf
         # block gradients -> full-size parameter gradients (zero outside the block), summed over the ranks when sharded

@@ -145,6 +145,15 @@ int fsw_graph_build_coalesced(const int64_t* recipients, const int64_t* senders,
 int fsw_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* V, int S, int64_t ldv,
                     float* Xp, int64_t ldp, float* x_copy, int64_t ld_copy, int32_t* stats, fsw_stream_t stream);
 
+/* ---- C[M, N] = beta * C + A^T . B for tall row-major A [K, lda >= M], B [K, ldb >= N] (K in the millions, M x N at most 16 blocks
+ * of 64 x 64): the weight-gradient shape of the backward pass -- gV = gXp^T . X (reference fsw_embedding.py:909-913 differentiated by
+ * torch.autograd) and the first Linear layer's gW (fsw_conv.py:361).  Exact fp32 products and sums (v_mfma_f32_32x32x2_f32); the K
+ * axis is split over the grid, the partial results are summed in a fixed order (no float atomics: bitwise reproducible).
+ * workspace: fsw_gemm_tn_workspace_bytes(M, N).                                                                            */
+size_t fsw_gemm_tn_workspace_bytes(int M, int N);
+int fsw_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, int M, int N, float* C, int64_t ldc, float beta,
+                    void* workspace, size_t workspace_bytes, fsw_stream_t stream);
+
 /* ---- unit-weight readout coefficients ------------------------------------------------------------
  * table[(D*(D-1)/2 + t) * ldt + k] = (1+xi_k) * [sin(2 pi xi_k (t+1)/D) - sin(2 pi xi_k t/D)] / (pi xi_k)
  * for 1 <= D <= max_deg, 0 <= t < D (the reference's Delta_t of fsw_embedding.py:1047-1075 times the

@@ -1103,6 +1103,34 @@ def test_backward_conv10k_training_step(dev):
     assert relerr(y2.cpu().numpy(), y.detach().cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("K,M,N", [(100_000, 256, 128), (70_001, 128, 385), (65_536, 40, 17), (200_003, 257, 129)])
+def test_gemm_tn_weight_gradient_shape(dev, K, M, N):
+    """csrc/gemm_tn.hip: A^T . B for tall A [K, M], B [K, N] (the weight gradients of the backward pass: gV = gXp^T . X and the first
+    Linear layer's gW, reductions over the rows) against float64; strided operands (gXp is read with its padded row stride); the
+    result is bitwise reproducible (partial sums combined in a fixed order); LinearTallFn's gradients equal torch's."""
+    from fsw_gnn_amd.fsw_embedding import gemm_tn, LinearTallFn
+    g = torch.Generator(device=dev).manual_seed(K)
+    Abig = torch.randn((K, M + 7), device=dev, generator=g)
+    A = Abig[:, :M]                                                  # row stride M + 7
+    B = torch.randn((K, N), device=dev, generator=g)
+    C = gemm_tn(A, B)
+    ref = A.double().t() @ B.double()
+    assert tuple(C.shape) == (M, N)
+    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert torch.equal(C, gemm_tn(A, B))
+    if M <= 128:
+        h = torch.randn((K, N), device=dev, generator=g, requires_grad=True)
+        W = torch.randn((M, N), device=dev, generator=g, requires_grad=True)
+        b = torch.randn(M, device=dev, generator=g, requires_grad=True)
+        R = torch.randn((K, M), device=dev, generator=g)
+        (LinearTallFn.apply(h, W, b) * R).sum().backward()
+        got = (h.grad.clone(), W.grad.clone(), b.grad.clone())
+        h.grad = W.grad = b.grad = None
+        (torch.nn.functional.linear(h, W, b) * R).sum().backward()
+        for a_, r_ in zip(got, (h.grad, W.grad, b.grad)):
+            assert float((a_ - r_).abs().max() / r_.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("n,E,d,out_ch,embed_dim,kw", [
     (500, 4000, 6, 10, None, {}),                                   # default embed_dim = 20 -> 19 slices, d % 4 != 0
     (1200, 9000, 64, 64, None, {}),                                 # default embed_dim = 128 -> 127 slices (odd)
