@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .coherence import minimize_mutual_coherence
-from .fsw_embedding import FSW_embedding, LinearTallFn, GEMM_TN_MIN_ROWS
+from .fsw_embedding import FSW_embedding, LinearSplitTallFn, LinearTallFn, GEMM_TN_MIN_ROWS
 from .graph import BuildHint, build_csr, build_csr_coalesced
 
 try:  # optional dependency, exactly the names the reference imports (fsw_conv.py:4-9)
@@ -336,6 +336,15 @@ class FSW_conv(_Base):
 
     def _tail(self, emb, vertex_features):
         """concat with the vertex features, MLP / dim_reduct, final BatchNorm through torch autograd (fsw_conv.py:357-369)."""
+        if (self._split_first_linear() and emb.is_cuda and emb.dtype == torch.float32 and emb.shape[0] >= GEMM_TN_MIN_ROWS
+                and self.mlp[0].weight.requires_grad and torch.is_grad_enabled() and vertex_features.shape[0] == emb.shape[0]):
+            # large training batches: the first Linear layer on the two operands where they lie (no concatenation), its weight
+            # gradient on csrc/gemm_tn.hip
+            out = LinearSplitTallFn.apply(emb, vertex_features.contiguous(), self.mlp[0].weight, self.mlp[0].bias,
+                                          self.message_weight_vs_self)
+            for m in self.mlp[1:]:
+                out = m(out)
+            return self.bn_final(out) if self.bn_final is not None else out
         h = torch.cat((self.message_weight_vs_self * emb, vertex_features), dim=-1) if self.concat_self else emb
         if (self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear) and h.is_cuda and h.dtype == torch.float32
                 and h.shape[0] >= GEMM_TN_MIN_ROWS and self.mlp[0].weight.requires_grad and torch.is_grad_enabled()):

@@ -1118,6 +1118,24 @@ def test_gemm_tn_weight_gradient_shape(dev, K, M, N):
     assert tuple(C.shape) == (M, N)
     assert float((C.double() - ref).abs().max() / ref.abs().max()) < 2e-6
     assert torch.equal(C, gemm_tn(A, B))
+    if M <= 128 and N > 64:
+        # the split form: y = [s * e | x] . W^T + b without the concatenation
+        from fsw_gnn_amd.fsw_embedding import LinearSplitTallFn
+        Ne = N - 33
+        e = torch.randn((K, Ne), device=dev, generator=g, requires_grad=True)
+        x = torch.randn((K, 33), device=dev, generator=g, requires_grad=True)
+        W = torch.randn((M, N), device=dev, generator=g, requires_grad=True)
+        b = torch.randn(M, device=dev, generator=g, requires_grad=True)
+        R = torch.randn((K, M), device=dev, generator=g)
+        y1 = LinearSplitTallFn.apply(e, x, W, b, 0.7)
+        (y1 * R).sum().backward()
+        got = [t_.grad.clone() for t_ in (e, x, W, b)]
+        e.grad = x.grad = W.grad = b.grad = None
+        y2 = torch.nn.functional.linear(torch.cat((0.7 * e, x), dim=1), W, b)
+        (y2 * R).sum().backward()
+        assert float((y1 - y2).abs().max() / y2.abs().max()) < 2e-6
+        for a_, r_ in zip(got, (e.grad, x.grad, W.grad, b.grad)):
+            assert float((a_ - r_).abs().max() / r_.abs().max()) < 2e-5
     if M <= 128:
         h = torch.randn((K, N), device=dev, generator=g, requires_grad=True)
         W = torch.randn((M, N), device=dev, generator=g, requires_grad=True)

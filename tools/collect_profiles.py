@@ -37,12 +37,13 @@ t["source"] = {"git_head": head, "captured": datetime.datetime.now().isoformat(t
                "how": "tools/refresh_profiles.sh %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py" % tag}
 json.dump(t, open(latest, "w"), indent=1)
 shutil.copy(latest, os.path.join(dst, name + "_pmc_traffic.json"))
-for sub, out in (("rmat22", "_rmat22_forward_kernel_stats.csv"), ("segcumsum", "_segcumsum_kernel_stats.csv")):
+for sub, out in (("rmat22", "_rmat22_forward_kernel_stats.csv"), ("segcumsum", "_segcumsum_kernel_stats.csv"),
+                 ("train", "_train_step_kernel_stats.csv")):
     try:
         shutil.copy(stats_of(sub), os.path.join(dst, name + out))
     except IndexError:
         print("no", sub, "profile in", src)
-for f in ("segcumsum.json",):
+for f in ("segcumsum.json", "skew_rmat20.log", "slice_shard_consumer.log", "slice_shard_exchange.log"):
     if os.path.isfile(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, name + "_" + f))
 print("profiles/%s_* written" % name)
