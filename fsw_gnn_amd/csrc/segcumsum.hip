@@ -191,7 +191,9 @@ struct SegTile {
 template <class V, class I, bool REV, bool VEC>
 __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
                                                                  const I* __restrict__ ids, int64_t n,
-                                                                 unsigned long long* __restrict__ desc, int64_t ntiles) {
+                                                                 unsigned long long* __restrict__ desc, int64_t ntiles, int use_halo) {
+  // use_halo = 0 for an IN-PLACE scan (out == values): the previous tile belongs to another workgroup, which may already have
+  // overwritten its values with its results -- the halo must be raw input, so such calls take the descriptor path for every tile
   using T = SegTile<V, I>;
   constexpr int EPL = T::EPL, Q = T::Q, GRP = T::GRP, WCH = T::WCH, NWV = T::NWV, TILE = T::TILE;
   constexpr int DW = DescWords<V>::kWords;
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     const int64_t L0 = tile * TILE + (int64_t)wv * WCH;
     t.has_prev = L0 > 0 && L0 < n;
     t.idprev = t.has_prev ? ids[mem(L0 - 1)] : I(0);
-    if (FSW_SEG_HALO && wv == 0 && tile > 0) {      // wave-uniform; the halo lies wholly inside the array (tile * TILE <= n - 1)
+    if (FSW_SEG_HALO && use_halo && wv == 0 && tile > 0) {      // wave-uniform; the halo lies wholly inside the array (tile * TILE <= n - 1)
       const int64_t L = tile * TILE - GRP + lane * EPL;
       if (VEC) {
         const int64_t m0 = REV ? mem(L + EPL - 1) : L;
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __rest
     SegPair<V> halo;
     halo.s = V(0);
     halo.f = 0;
-    if (FSW_SEG_HALO && wv == 0 && tile > 0) {
+    if (FSW_SEG_HALO && use_halo && wv == 0 && tile > 0) {
       const I idp = dpp_or_zero<kDppWaveShr1, 0xf>(cur.hid[EPL - 1]);
 #pragma unroll
       for (int u = 0; u < EPL; ++u) {
@@ -483,10 +485,15 @@ static int launch_segscan(const void* values, void* out, const void* ids, int64_
   constexpr int EPL = SegTile<V, I>::EPL;
   const bool vec = ((uintptr_t)values % (EPL * sizeof(V)) == 0) && ((uintptr_t)out % (EPL * sizeof(V)) == 0) &&
                    ((uintptr_t)ids % (EPL * sizeof(I)) == 0) && (!REV || n % EPL == 0);
+  // the halo shortcut reads other tiles' INPUT values: only when the output cannot overwrite them (any overlap of the two arrays
+  // counts as in place)
+  const char* vb = (const char*)values;
+  const char* ob = (const char*)out;
+  const int use_halo = (ob + n * sizeof(V) <= vb || vb + n * sizeof(V) <= ob) ? 1 : 0;
   if (vec)
-    k_segscan_chained<V, I, REV, true><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles);
+    k_segscan_chained<V, I, REV, true><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles, use_halo);
   else
-    k_segscan_chained<V, I, REV, false><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles);
+    k_segscan_chained<V, I, REV, false><<<grid, kSegThreads, 0, stream>>>((const V*)values, (V*)out, (const I*)ids, n, desc, ntiles, use_halo);
   FSW_LAUNCH_CHECK();
   return 0;
 }

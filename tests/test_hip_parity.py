@@ -738,9 +738,17 @@ def test_segcumsum_chained_scan_cases(dev, case):
         ip[1:] = t(ids, dev, torch.int64)
         got = segcumsum(vp[3:], ip[1:])
         assert np.abs(got.cpu().numpy() - ref).max() / scale < 3e-5
+        # in place: every tile takes the descriptor path (the halo shortcut would read values that another workgroup may already
+        # have overwritten with its results) -- and gives the same bits as the out-of-place call
         w = t(vals, dev, torch.float64)
+        sep = segcumsum(w, t(ids, dev, torch.int64))
         assert segcumsum(w, t(ids, dev, torch.int64), in_place=True).data_ptr() == w.data_ptr()
         assert np.abs(w.cpu().numpy() - ref).max() / scale < 1e-12
+        assert torch.equal(w, sep)
+        w32 = t(vals, dev, torch.float32)
+        sep32 = segcumsum(w32, t(ids, dev, torch.int32), reverse=True)
+        segcumsum(w32, t(ids, dev, torch.int32), in_place=True, reverse=True)
+        assert torch.equal(w32, sep32)
 
 
 def test_legacy_abi_drives_reference_hierarchy(dev):

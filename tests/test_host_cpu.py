@@ -308,3 +308,22 @@ def test_bench_self_launch_command_and_relay(tmp_path, capfd):
         assert bench.self_launch(a2, ["--gpus", "2"], script=str(script)) != 0      # a failing rank fails the run
     finally:
         del os.environ["FAKE_RC"]
+
+
+def test_build_hint_is_per_owner_and_never_risks_an_unknown_graph():
+    """graph.BuildHint (replaces round 2's module-global heuristic): the two-level CSR build only once THIS owner has seen a graph
+    without hub rows, back to the LSD build after a skewed one, per shape memory, and no coupling between two owners."""
+    from fsw_gnn_amd.graph import BuildHint, TWO_LEVEL_MAX_DEGREE
+    a, b = BuildHint(), BuildHint()
+    assert not a.two_level(1000, 5000)                       # nothing seen yet: the safe build
+    a.note(1000, 5000, 30)
+    assert a.two_level(1000, 5000) and a.two_level(2000, 9000)
+    assert not b.two_level(1000, 5000)                       # another layer has learnt nothing from it
+    a.note(4000, 64000, TWO_LEVEL_MAX_DEGREE + 1)            # a skewed graph
+    assert not a.two_level(4000, 64000) and not a.two_level(1000, 5000)
+    a.note(1000, 5000, 27)                                   # the stream of graphs is tame again ...
+    assert a.two_level(1000, 5000) and not a.two_level(4000, 64000)   # ... but the shape that showed hubs stays on the LSD build
+    a.note(4000, 64000, 100)
+    assert a.two_level(4000, 64000)
+    import fsw_gnn_amd.graph as G
+    assert not hasattr(G, "_skewed_shapes") and not hasattr(G, "_last_graph_skewed")
