@@ -250,7 +250,7 @@ def sharded_kernel_roofline(conv, x, ei, n, reps, dev, rank, world, consumer):
         wq, _ = conv._fused_weight(col0=0 if rank == 0 else 1 + ka, K=hm + Sl, want_w2=False)
         y = torch.empty((n, H), dtype=torch.float32, device=dev)
         a = emb.make_args(graph, st, prepared["Xp"], prepared["ldp"], fr, Sl, prepared["table"], None, 0, None, 1.0, hm, slice_offset=ka)
-        kms = timed_ms(lambda: _lib.check(L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0.0,
+        kms = timed_ms(lambda: _lib.check(L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0, 0.0,
                                                                y.data_ptr(), y.stride(0), stream), "fused"), reps, dev)
         alg_bytes = 4.0 * edges * Sl + 4.0 * edges + 8.0 * n + 4.0 * n * H
         kernel = "k_conv_fused_unit"
@@ -455,14 +455,22 @@ def weak_scaling_leg(args, x, ei, e_coalesced, dev, world, rank):
             conv.enable_slice_parallel(None, mode="consumer", chunks=args.chunks or None, output="replicated", stats=st)
     except Exception as e:   # noqa: BLE001
         ok, err = False, "%s: %s" % (type(e).__name__, e)
-    if not all_ranks_ok(ok, dev, world):
-        return {"error": err if not ok else "another rank failed to set the leg up"}
-
     def step():
         with torch.no_grad():
             return conv(x, ei)
 
-    elapsed, _ = timed_steps(step, args.warmup, args.steps, dev, world)
+    if ok and world == 1:
+        try:
+            step()                      # configuration errors show here, before the timed region
+        except Exception as e:   # noqa: BLE001
+            ok, err = False, "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_ok(ok, dev, world):
+        return {"error": err if not ok else "another rank failed to set the leg up"}
+    try:
+        # N > 1: a configuration error raises on every rank alike, before the step's first collective
+        elapsed, _ = timed_steps(step, args.warmup, args.steps, dev, world)
+    except NotImplementedError as e:
+        return {"error": "NotImplementedError: %s" % e}
     return {"scaling": "weak", "slices_per_gpu": WEAK_SLICES_PER_GPU, "slices": S, "n_gpus": world,
             "ms_per_step": elapsed / args.steps * 1e3, "value": float(e_coalesced) * S * args.steps / elapsed,
             "unit": "edges*slices/sec", "form": st.get("mode", "single GPU"), "collective": st.get("collective"),

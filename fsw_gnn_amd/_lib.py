@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FSW_HIP_LIBRARY: another build of the same library (kernel tuning experiments, tools/exp_variants.sh)
 LIB_PATH = os.environ.get("FSW_HIP_LIBRARY") or os.path.join(_HERE, "libfsw_hip.so")
 
-FSW_ABI_VERSION = 4
+FSW_ABI_VERSION = 5
 REG_MAX_DEG = 32
 LDS_MAX_DEG = 2048
 MID_SIZES = (40, 48, 64, 80, 96, 128, 160, 192, 256)   # FSW_MID_SIZES: padded register-path networks above REG_MAX_DEG
@@ -76,7 +76,7 @@ _SIGNATURES = {
     "fsw_pack_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_int, c_vp, c_i64, c_vp]),
     "fsw_project_linear_f32": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_vp, ctypes.c_int, c_i64, c_vp, c_i64,
                                               c_vp, ctypes.c_int, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, c_vp, c_i64,
+    "fsw_conv_fused_f32": (ctypes.c_int, [ctypes.POINTER(EmbedArgs), c_vp, c_i64, c_vp, ctypes.c_int, c_vp, c_i64, ctypes.c_int,
                                           ctypes.c_int, c_f32, c_vp, c_i64, c_vp]),
     "fsw_add_bias_act_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, ctypes.c_int, ctypes.c_int, c_f32, c_vp]),
     "fsw_unit_dcoeff_table": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_i64, c_vp]),

@@ -58,8 +58,9 @@ struct FusedArgs {
   const float* Wq;  // packed W1^T: [Kp/8][ldw][8], zero padded (Kp = K rounded up to 8, ldw = Hout rounded up to 32)
   int64_t ldw;
   const float* lin_bias;  // [Hout] or null; used only when y_accumulate == 0
-  const float* Yin;       // [n][ldyin] x . W2^T + b in perm order (written by the projection kernel) or null
-  int64_t ldyin;
+  const float* Yin;       // [n][ldyin] x . W2^T + b or null: in perm order (written by the projection kernel), or by node id when
+  int64_t ldyin;          // yin_by_node (the block comes from a BLAS GEMM: no row permutation needed, whole 4 Hout-byte rows are read)
+  int yin_by_node;
   int Hout;
   int act;  // 0 none, 1 relu, 2 leaky relu
   float slope;
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
     for (int q = 0; q < 16; ++q) {
       const int row = wv * 8 + (q >> 1), c = lane + 64 * (q & 1);
       yin[q] = 0.f;
-      if ((ABL & 2) == 0 && a.Yin && row < nrows && c < a.Hout) yin[q] = a.Yin[(int64_t)(p + row) * a.ldyin + c];
+      if ((ABL & 2) == 0 && a.Yin && row < nrows && c < a.Hout)
+        yin[q] = a.Yin[(int64_t)(a.yin_by_node ? a.perm[p + row] : p + row) * a.ldyin + c];
     }
     __syncthreads();
     f32x16 acc;
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;     // C/D map of the 32x32 MFMA
-      yin[r] = (a.Yin && row < nrows && j < a.Hout) ? a.Yin[(int64_t)(p + row) * a.ldyin + j] : 0.f;
+      yin[r] = (a.Yin && row < nrows && j < a.Hout) ? a.Yin[(int64_t)(a.yin_by_node ? a.perm[p + row] : p + row) * a.ldyin + j] : 0.f;
     }
     f32x16 acc;
     slab_mma<ABL>(a, H, slab, fr, fh, acc);
@@ -383,7 +385,7 @@ extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
 }
 
 extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
-                                  const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy,
+                                  const float* Yin, int64_t ldyin, int yin_by_node, int act, float slope, float* Y, int64_t ldy,
                                   fsw_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   FSW_REQUIRE(args && Wq && Y, "fsw_conv_fused_f32: null pointer");
@@ -402,7 +404,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   a.rowptr = e.rowptr; a.col = e.col; a.perm = e.perm; a.bin_start = e.bin_start;
   a.Xp = e.Xp; a.ldp = e.ldp; a.S = e.S; a.table = e.unit_table; a.ldt = e.ldt;
   a.bias = e.bias; a.out_scale = e.out_scale; a.has_mass = e.has_mass; a.mass_fn = e.mass_fn; a.mass_scale = e.mass_scale;
-  a.Wq = Wq; a.ldw = ldw; a.lin_bias = lin_bias; a.Yin = Yin; a.ldyin = ldyin; a.Hout = Hout; a.act = act; a.slope = slope;
+  a.Wq = Wq; a.ldw = ldw; a.lin_bias = lin_bias; a.Yin = Yin; a.ldyin = ldyin; a.yin_by_node = yin_by_node ? 1 : 0; a.Hout = Hout; a.act = act; a.slope = slope;
   a.Y = Y; a.ldy = ldy;
   a.Kp = (e.has_mass + e.S + 7) & ~7;
   a.ldh = a.Kp | 1;

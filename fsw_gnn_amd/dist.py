@@ -356,7 +356,7 @@ def consumer_forward(conv, x, graph, prepared, scale, group=None, output="replic
                           chunk=c if graph.chunk_rows else None)
         # Y rows are addressed by node id: shift the base so that node c * cs lands on row 0 of Pc
         ybase = Pc.data_ptr() - c * cs * Pc.stride(0) * 4
-        rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0.0, ybase, Pc.stride(0), stream)
+        rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1], None, H, None, 0, 0, 0, 0.0, ybase, Pc.stride(0), stream)
         _lib.check(rc, "fsw_conv_fused_f32")
 
     # x . W2^T + b of the rows this rank will own after the reduce-scatter (row block `rank` of every chunk): ONE gather of

@@ -273,21 +273,23 @@ class FSW_conv(_Base):
             lin = self.mlp[0]
             wq, w2 = self._fused_weight()
             y = torch.empty((n, lin.out_features), dtype=x.dtype, device=x.device)
-            yin = torch.empty_like(y) if self.concat_self else None      # x . W2^T + b in degree-bin row order
-            # up to 128 features the projection kernel produces that block as four more 32-column slabs of the same pass; above,
-            # its slabs take a third pass over X (3.8 ms at 4M x 256), more than a BLAS GEMM + one row permutation (2.9 ms)
+            # up to 128 features the projection kernel produces x . W2^T + b as four more 32-column slabs of the same pass, rows in
+            # degree-bin order (contiguous runs for the fused kernel); above, its slabs would take a third pass over X (3.8 ms at
+            # 4M x 256): a BLAS GEMM writes the block in NODE order and the fused kernel reads whole rows of it by node id (no row
+            # permutation: 1.1 ms at 4M rows)
             in_kernel = self.concat_self and self.in_channels <= 128
+            by_node = self.concat_self and not in_kernel
+            yin = torch.empty_like(y) if in_kernel else None
             lin2 = (w2, lin.bias.detach() if lin.bias is not None else None, yin) if in_kernel else None
             prepared = emb_mod.prepare(x, graph, linear2=lin2)
-            if self.concat_self and not in_kernel:
-                y2 = torch.addmm(lin.bias.detach(), x, w2.t()) if lin.bias is not None else x @ w2.t()
-                torch.index_select(y2, 0, graph.perm.long(), out=yin)
+            if by_node:
+                yin = torch.addmm(lin.bias.detach(), x, w2.t()) if lin.bias is not None else x @ w2.t()
             st = prepared["stats"]
             if prepared["unit_fast"]:
-                next_module = self._fused_linear(graph, prepared, scale, wq, yin, y)     # every row of at most 32 neighbours
+                next_module = self._fused_linear(graph, prepared, scale, wq, yin, y, by_node)     # every row of at most 32 neighbours
                 nlong = st[_lib.STAT_NUM_LDS] + st[_lib.STAT_NUM_GLOBAL]
                 if nlong > 0:
-                    self._finish_long_rows(x, graph, prepared, scale, yin, y, next_module)
+                    self._finish_long_rows(x, graph, prepared, scale, yin, y, next_module, by_node)
                 for m in self.mlp[next_module:]:
                     y = m(y)
                 return y
@@ -416,7 +418,8 @@ class FSW_conv(_Base):
         parts = D.slice_partition(emb_mod.nSlices, world)
         mode = sp['mode']
         prepared = None
-        if world > 1 and mode in ('auto', 'consumer') and self._fusable() and parts[0][1] > parts[0][0]:
+        widest = max(b - a for a, b in parts)
+        if world > 1 and mode in ('auto', 'consumer') and self._fusable(widest) and parts[0][1] > parts[0][0]:
             prepared = emb_mod.prepare(x, graph, slice_range=parts[rank])
             st = prepared["stats"]
             if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
@@ -495,8 +498,10 @@ class FSW_conv(_Base):
     fuse_linear = True   # class-level switch: set conv.fuse_linear = False to force the unfused kernels
     cache_graph = False  # set conv.cache_graph = True to reuse the CSR while edge_index is unchanged
 
-    def _fusable(self):
-        """Static conditions of the fused embedding + Linear kernel (csrc/conv_fused.hip)."""
+    def _fusable(self, num_slices=None):
+        """Static conditions of the fused embedding + Linear kernel (csrc/conv_fused.hip).  num_slices: the width of the slice block
+        one call covers (default: all slices; under slice sharding a rank's block -- a layer too wide for the fused tile on one GPU
+        fits it once its slices are spread over the ranks: BASELINE config 4, 1024 slices as 128 per GPU)."""
         emb = self.fsw_embed
         if not (self.fuse_linear and self.mlp is not None and isinstance(self.mlp[0], torch.nn.Linear)):
             return False
@@ -504,7 +509,8 @@ class FSW_conv(_Base):
             return False
         if emb.encode_total_mass and emb.total_mass_encoding_method != 'plain':
             return False
-        return int(_lib.lib().fsw_conv_fused_lds_bytes(emb.nSlices, 1 if emb.encode_total_mass else 0)) <= 64 * 1024
+        width = emb.nSlices if num_slices is None else int(num_slices)
+        return int(_lib.lib().fsw_conv_fused_lds_bytes(width, 1 if emb.encode_total_mass else 0)) <= 64 * 1024
 
     def _fused_weight(self, col0=0, K=None, want_w2=True):
         """(Wq, W2) of the first Linear layer W = [W1 | W2]: K columns of W1 from column col0 (default: all embed_dim
@@ -527,7 +533,7 @@ class FSW_conv(_Base):
         _lib.check(rc, "fsw_pack_linear_f32")
         return wq, w2
 
-    def _finish_long_rows(self, x, graph, prepared, scale, yin, y, next_module):
+    def _finish_long_rows(self, x, graph, prepared, scale, yin, y, next_module, yin_by_node=False):
         """Rows above REG_MAX_DEG neighbours of a layer that otherwise runs the fused kernel: their embeddings come from the
         long-row kernels (mid / wave-sort / hub / giant), the first Linear layer for those rows from one GEMM on the gathered
         rows.  A graph with a few hubs keeps the fused kernel for everything else."""
@@ -541,15 +547,15 @@ class FSW_conv(_Base):
         emb_mod.embed_into(x, graph, emb, out_scale=scale, prepared=prepared, long_rows_only=True)
         el = emb.index_select(0, rows)
         W1 = lin.weight.detach()[:, :E]
-        if yin is not None:                       # x . W2^T + b of these rows: rows p0..p1-1 of the degree-ordered block
-            yl = torch.addmm(yin[p0:p1], el, W1.t())
+        if yin is not None:                       # x . W2^T + b of these rows: rows p0..p1-1 of the degree-ordered block (or by node id)
+            yl = torch.addmm(yin.index_select(0, rows) if yin_by_node else yin[p0:p1], el, W1.t())
         else:
             yl = torch.addmm(lin.bias.detach(), el, W1.t()) if lin.bias is not None else el @ W1.t()
         if next_module == 2:
             yl = self.mlp[1](yl)
         y.index_copy_(0, rows, yl)
 
-    def _fused_linear(self, graph, prepared, scale, wq, yin, y):
+    def _fused_linear(self, graph, prepared, scale, wq, yin, y, yin_by_node=False):
         L = _lib.lib()
         emb = self.fsw_embed
         lin = self.mlp[0]
@@ -565,7 +571,7 @@ class FSW_conv(_Base):
         rc = L.fsw_conv_fused_f32(ctypes.byref(a), wq.data_ptr(), wq.shape[1],
                                   lin.bias.data_ptr() if lin.bias is not None else None, lin.out_features,
                                   yin.data_ptr() if yin is not None else None, yin.stride(0) if yin is not None else 0,
-                                  act, slope, y.data_ptr(), y.stride(0),
+                                  1 if yin_by_node else 0, act, slope, y.data_ptr(), y.stride(0),
                                   torch.cuda.current_stream(y.device).cuda_stream)
         _lib.check(rc, "fsw_conv_fused_f32")
         return next_module
@@ -614,10 +620,9 @@ class FSW_conv(_Base):
             xl = x[r0:r0 + nl]
             if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
                 yin = None
-                if self.concat_self:                            # x . W2^T + b of the local rows, in degree-bin order
+                if self.concat_self:                            # x . W2^T + b of the local rows, read by (local) node id
                     yin = torch.addmm(lin.bias, xl, w2.t()) if lin.bias is not None else xl @ w2.t()
-                    yin = yin.index_select(0, graph.perm.long())
-                assert self._fused_linear(graph, prepared, scale, wq, yin, y_loc[:nl]) == next_module
+                assert self._fused_linear(graph, prepared, scale, wq, yin, y_loc[:nl], yin is not None) == next_module
             else:                                               # long rows: unfused kernels on the local rows
                 E = self.embed_dim
                 buf = torch.empty((nl, E + self.in_channels if self.concat_self else E), dtype=x.dtype, device=x.device)

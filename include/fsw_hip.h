@@ -33,7 +33,7 @@ extern "C" {
 
 typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
 
-#define FSW_ABI_VERSION 4
+#define FSW_ABI_VERSION 5
 
 /* Degree classes of the fused neighbourhood kernels.  Rows are binned by in-degree:
  *   bin b, 0 <= b <= FSW_REG_MAX_DEG : rows of degree exactly b (register path, one wave per row and
@@ -225,7 +225,8 @@ int fsw_embed_f32(const fsw_embed_args* args, fsw_stream_t stream);
  *                           the block is stored at Y2[row_map[i]] when row_map != NULL -- pass the graph's
  *                           invperm so that every workgroup of the fused kernel reads one contiguous run;
  *   fsw_conv_fused_f32      neighbourhood kernel + E . W1^T on the fp32 matrix cores; with Yin != NULL it
- *                           adds row invperm-position p of Yin [n, ldyin] (else lin_bias), applies the
+ *                           adds row invperm-position p of Yin [n, ldyin] -- or, with yin_by_node != 0, row `node` of a Yin kept
+ *                           in node order (a block that a BLAS GEMM produced: no row permutation) -- else lin_bias, applies the
  *                           activation (0 none, 1 relu, 2 leaky relu with `slope`) and stores Y [n, ldy].
  * Preconditions of fsw_conv_fused_f32: unit weights (args->w == NULL), tau <= 1, fsw_conv_fused_lds_bytes() <= 64 KiB.
  * It computes the rows of in-degree 0 .. FSW_REG_MAX_DEG; rows above that are left untouched in Y -- the caller runs
@@ -248,7 +249,8 @@ int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t ldx, const 
                            float* Xp, int64_t ldp, const float* W2, int H2, int64_t ldw2, const float* b2, float* Y2,
                            int64_t ldy2, const int32_t* row_map, int32_t* stats, fsw_stream_t stream);
 int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, int64_t ldw, const float* lin_bias, int Hout,
-                       const float* Yin, int64_t ldyin, int act, float slope, float* Y, int64_t ldy, fsw_stream_t stream);
+                       const float* Yin, int64_t ldyin, int yin_by_node, int act, float slope, float* Y, int64_t ldy,
+                       fsw_stream_t stream);
 /* R[r, c] = act(R[r, c] + Yin[r, c] + bias[c]) for rows x H floats in place, one launch (Yin, bias may be NULL; act as in
  * fsw_conv_fused_f32).  Epilogue of the slice-sharded layer forms (fsw_gnn_amd/dist.py): the rows a rank owns after the
  * reduce-scatter of the partial sums receive x . W2^T + b (reference fsw_conv.py:357-362, the vertex-feature half of mlp[0]) and

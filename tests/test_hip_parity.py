@@ -1387,6 +1387,16 @@ with torch.no_grad():
     conv2.enable_slice_parallel(None, mode="exchange", chunks=2)
     assert rel(conv2(X, ei), ref_bn) < 1e-5                        # Linear -> BatchNorm (eval) -> act -> Linear tail on the owned rows
     conv2.enable_slice_parallel(None, enabled=False)
+    # 2d. a layer too wide for the fused tile on ONE GPU (512 slices) takes the consumer form once its slices are spread over the
+    # ranks (BASELINE config 4's situation: 1024 slices as 128 per GPU)
+    torch.manual_seed(9)
+    convw_ = FSW_conv(d, 12, embed_dim=513, device=dev)
+    assert not convw_._fusable() and convw_._fusable(512 // world)
+    ref_w = convw_(X, ei)
+    convw_.enable_slice_parallel(None, mode="consumer", chunks=2, stats=st)
+    yw_ = convw_(X, ei)
+    assert st["mode"] == "consumer" and rel(yw_, ref_w) < 2e-6, rel(yw_, ref_w)
+    del convw_
     # 3. auto on a graph with long rows: the consumer form does not apply, the gather form takes over
     ei2 = torch.cat([ei, torch.stack([torch.arange(300, device=dev), torch.full((300,), 2999, device=dev)]),
                      torch.stack([torch.arange(50, device=dev), torch.full((50,), 5, device=dev)])], dim=1)
