@@ -739,16 +739,20 @@ def test_segcumsum_chained_scan_cases(dev, case):
         got = segcumsum(vp[3:], ip[1:])
         assert np.abs(got.cpu().numpy() - ref).max() / scale < 3e-5
         # in place: every tile takes the descriptor path (the halo shortcut would read values that another workgroup may already
-        # have overwritten with its results) -- and gives the same bits as the out-of-place call
+        # have overwritten with its results).  With segments shorter than a tile the carry is the predecessor's aggregate either
+        # way -- the same operations in the same order -- so in place and out of place give the same bits; with segments that span
+        # tiles the look-back adds aggregates and prefixes in whatever state it finds them (sums equal to rounding, not to the bit)
         w = t(vals, dev, torch.float64)
         sep = segcumsum(w, t(ids, dev, torch.int64))
         assert segcumsum(w, t(ids, dev, torch.int64), in_place=True).data_ptr() == w.data_ptr()
         assert np.abs(w.cpu().numpy() - ref).max() / scale < 1e-12
-        assert torch.equal(w, sep)
         w32 = t(vals, dev, torch.float32)
         sep32 = segcumsum(w32, t(ids, dev, torch.int32), reverse=True)
         segcumsum(w32, t(ids, dev, torch.int32), in_place=True, reverse=True)
-        assert torch.equal(w32, sep32)
+        if case in ("short", "all_heads"):
+            assert torch.equal(w, sep) and torch.equal(w32, sep32)
+        else:
+            assert float((w32 - sep32).abs().max()) <= 3e-5 * scale
 
 
 def test_legacy_abi_drives_reference_hierarchy(dev):
