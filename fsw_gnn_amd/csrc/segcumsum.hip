@@ -188,8 +188,11 @@ struct SegTile {
   I hid[EPL];        // l * EPL .. of that group) -- see the look-back
 };
 
+#ifndef FSW_SEG_MINWAVES
+#define FSW_SEG_MINWAVES 1   // waves per SIMD the kernel is compiled for (register cap); measured: tools/r3_run9.sh
+#endif
 template <class V, class I, bool REV, bool VEC>
-__global__ void __launch_bounds__(kSegThreads) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
+__global__ void __launch_bounds__(kSegThreads, FSW_SEG_MINWAVES) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
                                                                  const I* __restrict__ ids, int64_t n,
                                                                  unsigned long long* __restrict__ desc, int64_t ntiles, int use_halo) {
   // use_halo = 0 for an IN-PLACE scan (out == values): the previous tile belongs to another workgroup, which may already have
