@@ -40,6 +40,9 @@ constexpr int kLdT = 132;   // LDS row stride of the staged output tile (Hout <=
 #ifndef FSW_FUSED_PREFETCH
 #define FSW_FUSED_PREFETCH 8
 #endif
+#ifndef FSW_FUSED_NARROW_WAVES
+#define FSW_FUSED_NARROW_WAVES 4   // waves per SIMD the narrow-block variant (RPW = 2) is compiled for; measured: tools/r3_run10.sh
+#endif
 
 struct FusedArgs {
   const int32_t* rowptr;
@@ -423,7 +426,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   FSW_ABL_CASE(1) FSW_ABL_CASE(2) FSW_ABL_CASE(4) FSW_ABL_CASE(6) FSW_ABL_CASE(7)
 #endif
   if (e.S <= kWave / 2)   // a narrow slice block: two rows per wavefront (fused_embed_rows)
-    k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4, 0, 2><<<(unsigned)nblocks, 256, lds, stream>>>(a);
+    k_conv_fused_unit<0, FSW_REG_MAX_DEG, FSW_FUSED_NARROW_WAVES, 0, 2><<<(unsigned)nblocks, 256, lds, stream>>>(a);
   else
     k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4><<<(unsigned)nblocks, 256, lds, stream>>>(a);
   FSW_LAUNCH_CHECK();

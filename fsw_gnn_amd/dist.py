@@ -312,7 +312,20 @@ def reduce_scatter_pipeline(compute_partial, finish_rows, num_chunks, chunk_rows
     return R, row0
 
 
-def consumer_forward(conv, x, graph, prepared, scale, group=None, output="replicated", stats=None):
+def consumer_weight(conv, group=None):
+    """This rank's columns of the first Linear layer packed for the fused kernel (one launch; callers issue it BEFORE the forward's
+    device->host stats read so that it does not sit in the gap behind it)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    emb = conv.fsw_embed
+    has_mass = 1 if emb.encode_total_mass else 0
+    ka, kb = slice_partition(emb.nSlices, world)[rank]
+    K = (has_mass if rank == 0 else 0) + (kb - ka)
+    if K == 0:
+        return None
+    return conv._fused_weight(col0=0 if rank == 0 else has_mass + ka, K=K, want_w2=False)[0]
+
+
+def consumer_forward(conv, x, graph, prepared, scale, group=None, output="replicated", stats=None, wq=None):
     """FSW_conv's slice-sharded fused layer (see the module docstring).  Preconditions checked by the caller:
     conv._fusable(), unit-weight graph without rows above 32 neighbours, prepared = projection of this rank's block."""
     L = _lib.lib()
@@ -333,9 +346,9 @@ def consumer_forward(conv, x, graph, prepared, scale, group=None, output="replic
     elif len(conv.mlp) > 1 and isinstance(conv.mlp[1], torch.nn.ReLU):
         act, next_module = 1, 2
     st = prepared["stats"]
-    wq = None
     if K > 0:
-        wq, _ = conv._fused_weight(col0=0 if rank == 0 else has_mass + ka, K=K, want_w2=False)
+        if wq is None:
+            wq = consumer_weight(conv, group)
         bias = None
         if emb.enable_bias:
             b = emb.bias.detach()

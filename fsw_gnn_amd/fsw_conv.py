@@ -420,10 +420,11 @@ class FSW_conv(_Base):
         prepared = None
         widest = max(b - a for a, b in parts)
         if world > 1 and mode in ('auto', 'consumer') and self._fusable(widest) and parts[0][1] > parts[0][0]:
+            wq = D.consumer_weight(self, group)              # queued ahead of the stats read inside prepare()
             prepared = emb_mod.prepare(x, graph, slice_range=parts[rank])
             st = prepared["stats"]
             if prepared["unit_fast"] and st[_lib.STAT_NUM_LDS] == 0 and st[_lib.STAT_NUM_GLOBAL] == 0:
-                res, next_module = D.consumer_forward(self, x, graph, prepared, scale, group, sp['output'], stats)
+                res, next_module = D.consumer_forward(self, x, graph, prepared, scale, group, sp['output'], stats, wq=wq)
                 if stats is not None:
                     stats["mode"] = "consumer"
                 if sp['output'] == 'sharded':
