@@ -15,6 +15,7 @@
 // sweeps as in the forward; the contribution is scattered to element order inside the wave's scratch and then added
 // with one 4-byte atomic per neighbour (these rows are few).
 #include <algorithm>
+#include <stdlib.h>
 #include "fsw_common.h"
 #include "sortnet.h"
 #include "wave_sort.h"
@@ -247,6 +248,87 @@ __global__ void __launch_bounds__(256, (M <= 16 ? 2 : 1)) k_embed_wsort_bwd(cons
   }
 }
 
+// ---- 129 .. 2048 neighbours, unit weights, key gradients STORED (the store-and-sum backward): the forward's quad structure ----
+// k_embed_wsort_bwd above stages a [slices][elements] tile of up to 140 KB in LDS (one workgroup of four wavefronts per CU) and
+// gathers 4 bytes per lane; on the RMAT-20 graph its three instances took 33 ms of a 75 ms training step, 7-13 x their forward
+// counterparts.  Here, as in k_embed_hub_quad (embed_hub.hip): the four wavefronts of a workgroup own four ADJACENT slices of one
+// row (S % 4 == 0), wavefront w gathers a quarter of the row as float4 = slices k0 .. k0 + 3 and the lines change hands through
+// LDS; every wavefront sorts its line as packed (key, element index) words in registers, walks it (walk_line: coefficients and
+// their frequency derivatives by float64 rotation) and drops g * C into the element's place of ITS line of the same LDS buffer;
+// the workgroup then stores the four slices of every element as ONE 16-byte piece of gkey[entry, k0 .. k0 + 3].  4 .. 32 KB of LDS
+// and two to four waves per SIMD.  The atomics form (gkey == NULL), general weights and edge features stay on the kernel above.
+template <int M>
+__global__ void __launch_bounds__(256, (M >= 32 ? 2 : (M >= 16 ? 3 : 4))) k_embed_quad_bwd(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi, const float* __restrict__ Xp, int64_t ldp, int S,
+    const float* __restrict__ freqs, const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale, float* __restrict__ gfreq,
+    float* __restrict__ gkey, int64_t ldk) {
+  constexpr int CAP = M * kWave;
+  constexpr int NQ = M >= 4 ? M / 4 : 1;            // float4 gathers per lane
+  static_assert(M % 4 == 0, "keys per lane: a multiple of 4");
+  __shared__ __attribute__((aligned(16))) float xq[4][CAP];
+  const int pbeg = bin_start[bin_lo], nrows = bin_start[bin_hi + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  const int xcd = blockIdx.x & 7;
+  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
+    const int64_t i = (vb >> 3) * 4;              // the workgroup's first slice; S % 4 == 0: four slices of one row
+    const int64_t rl = i / S;
+    const int k0 = (int)(i - rl * S);
+    const int64_t r = rl * 8 + xcd;
+    if (r >= nrows) return;                       // the whole workgroup
+    const int node = perm[pbeg + r];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    const int32_t* colrow = col + start;
+    const float* xr = Xp + k0;
+    int c[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) c[q] = colrow[min((q * 4 + w) * kWave + lane, D - 1)];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int t = (q * 4 + w) * kWave + lane;
+      float4 v = *reinterpret_cast<const float4*>(xr + (int64_t)c[q] * ldp);
+      if (t >= D) v = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+      xq[0][t] = v.x;
+      xq[1][t] = v.y;
+      xq[2][t] = v.z;
+      xq[3][t] = v.w;
+    }
+    __syncthreads();
+    WaveLine64<M> ln;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const int t = j * kWave + lane;               // striped: conflict-free reads; the index travels with the key
+      ln.e[j] = pack_key_index(xq[w][t], t);
+    }
+    ln.sort();
+    const int k = k0 + w;
+    const double xi = (double)freqs[k];
+    const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
+    // every lane of THIS wavefront has read the line (the sort needed all keys): its places may take the results
+    float gf = walk_line<M, false>(
+        ln, lane * M, D, D, xi, 1.0 / (double)D, gi, 0.0, [](int) { return 0.f; }, [&](int id, float v) { xq[w][id] = v; });
+    gf = wave_sum_b(gf);
+    if (lane == 0 && gfreq) atomicAdd(gfreq + k, gf);
+    __syncthreads();
+    for (int e = threadIdx.x; e < D; e += blockDim.x)
+      *reinterpret_cast<float4*>(gkey + (int64_t)(start + e) * ldk + k0) = make_float4(xq[0][e], xq[1][e], xq[2][e], xq[3][e]);
+    __syncthreads();                               // the next row overwrites the buffer
+  }
+}
+
+template <int M>
+static int launch_quad_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, const float* g, int64_t ldg, float* gfreq,
+                           float* gkey, int64_t ldk, hipStream_t stream) {
+  rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
+  if (rows_upper <= 0) return 0;
+  const int64_t nvirtual = ceil_div(rows_upper, 8) * (a.S / 4) * 8;
+  k_embed_quad_bwd<M><<<(unsigned)std::min<int64_t>(nvirtual, 1ll << 20), 256, 0, stream>>>(
+      a.rowptr, a.col, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp, a.S, a.freqs, g, ldg, a.has_mass, a.out_scale, gfreq, gkey, ldk);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- rows above FSW_LDS_MAX_DEG ------------------------------------------------------------------------------------------
 // fences below: workgroup scope orders a wave's scratch stores before its own later loads (same CU, same L1; see embed_wsort.hip)
 constexpr int kSweepDepthB = 4;
@@ -437,7 +519,15 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
   // 33 .. 128: one lane per slice (embed_mid_bwd.hip)
   if ((rc = launch_embed_mid_bwd(a, rows_upper, g, ldg, gXp, ldgp, gfreq, gkey, ldk, stream))) return rc;
   constexpr int kFirst = FSW_BIN_MID0 + 6;                     // first bin above FSW_MID_MAX_DEG_WEIGHTED = 128
-  if (unit) {   // a wave holds 64 M elements
+  // unit weights with stored key gradients (the store-and-sum backward) and four-slice alignment: the quad kernels
+  const bool quad = unit && gkey && !a.efeat && a.S % 4 == 0 && ldk % 4 == 0 && a.ldp % 4 == 0 && ((uintptr_t)gkey & 15) == 0 &&
+                    ((uintptr_t)a.Xp & 15) == 0 && !getenv("FSW_BWD_QUAD_OFF");
+  if (quad) {
+    if ((rc = launch_quad_bwd<4>(a, kFirst, FSW_BIN_LDS0 - 1, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;   // 129 .. 256
+    if ((rc = launch_quad_bwd<8>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
+    if ((rc = launch_quad_bwd<16>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
+    if ((rc = launch_quad_bwd<32>(a, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
+  } else if (unit) {   // a wave holds 64 M elements
     FSW_WB(4, false, kFirst, FSW_BIN_LDS0 - 1);                // 129 .. 256
     FSW_WB(8, false, FSW_BIN_LDS0, FSW_BIN_LDS0);
     FSW_WB(16, false, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1);

@@ -940,6 +940,35 @@ def test_backward_long_rows_lds_and_global_paths(dev):
         assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
 
 
+@pytest.mark.parametrize("S", [10, 12])
+def test_backward_rows_of_129_to_2048_neighbours_every_class(dev, S):
+    """Gradients through rows at both ends of the classes 129..256 / ..512 / ..1024 / ..2048, unit weights, against the oracle's
+    analytic backward evaluated with the same float32 sort order.  S = 12 (a multiple of 4): the store-and-sum backward takes
+    k_embed_quad_bwd (16-byte gathers dealt through LDS, packed (key, index) lines in registers, 16-byte stores of the key gradients);
+    S = 10: the LDS-tile kernels k_embed_wsort_bwd.  Both must give the same gradients to rounding."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(31)
+    sizes = [129, 256, 257, 512, 513, 1024, 1025, 2048, 200, 300, 700, 1500]
+    nrows, n, d = len(sizes), 2100, 9
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    V = cases.synth.unit_slices(S, d, seed=91)
+    fr = cases.random_freqs(S, seed=92)
+    fr[1] = 0.0
+    rec = np.repeat(np.arange(nrows), sizes).astype(np.int64)
+    snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    R = rng.standard_normal((nrows, S))
+    E = make_embedding(dev, V, fr, enable_bias=False, learnable_slices=True, learnable_freqs=True)
+    Xd = t(X, dev).requires_grad_(True)
+    graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None, nrows, n)
+    out = E.embed_autograd(Xd, graph)
+    (out * t(R, dev)).sum().backward()
+    gX, gV, gxi = O.fsw_embed_csr_backward(X, rowptr, snd, np.ones(rec.size), V, fr, R, Xp_override=_hip_projection(E, Xd))
+    assert relerr(Xd.grad.cpu().numpy(), gX) < 2e-5
+    assert relerr(E.projVecs.grad.cpu().numpy(), gV) < 2e-5
+    assert relerr(E.freqs.grad.cpu().numpy(), gxi) < 2e-5
+
+
 def test_hub_row_with_100k_neighbours_forward_and_backward(dev):
     """A star: 100 000 leaves send to vertex 0 (64 register-sorted chunks, six merge levels over the scratch line), a
     second row of 9 000; unit and general weights; forward against the C oracle, gradients against the oracle's analytic
