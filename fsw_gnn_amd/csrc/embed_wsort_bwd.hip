@@ -329,105 +329,6 @@ static int launch_quad_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int6
   return 0;
 }
 
-// ---- 2049 .. 16384 neighbours, unit weights, key gradients stored: the line in the registers of NW wavefronts ----------------------
-// The forward's multi-wavefront structure (embed_hub.hip: k_embed_hub<NW, M>) with packed (key, element index) words: every wavefront
-// gathers and sorts its chunk of 1024 elements (16 per lane), the merge levels above one wavefront exchange the 64-bit words through
-// LDS (one ds_write_b64 + one ds_read_b64 per element and exchange, a wave-uniform min-or-max), then every lane walks its ranks
-// (walk_line) and stores g * C straight into gkey[entry, k].  Replaces, for these rows, the scratch-line kernel below (one wavefront
-// per line sweeping a global scratch region: 15.7 ms for 1.1M edges on the RMAT-20 graph, 7 x its forward).
-template <int M>
-__device__ __forceinline__ void wave_exchange64(WaveLine64<M>& ln, unsigned long long* __restrict__ xb, int w, int lane, int partner,
-                                                bool mirrored, bool lower) {
-  constexpr int CAP = M * kWave;
-  unsigned long long* mine = xb + w * CAP + lane;
-  asm volatile("" : "+v"(mine));                 // one base register, immediate offsets (see wave_exchange in embed_hub.hip)
-#pragma unroll
-  for (int j = 0; j < M; ++j) mine[j * kWave] = ln.e[j];
-  __syncthreads();
-  const unsigned long long* theirs = xb + partner * CAP + (mirrored ? kWave - 1 - lane : lane);
-  asm volatile("" : "+v"(theirs));
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-    const unsigned long long o = theirs[(mirrored ? M - 1 - j : j) * kWave];
-    const bool take = lower ? (o < ln.e[j]) : (o > ln.e[j]);
-    ln.e[j] = take ? o : ln.e[j];
-  }
-  __syncthreads();
-}
-
-template <int NW, int M>
-__global__ void __launch_bounds__(NW* kWave) k_embed_hub_bwd(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
-                                                            int bin_lo, int bin_hi, int dmin, int dmax, const float* __restrict__ Xp,
-                                                            int64_t ldp, int S, const float* __restrict__ freqs,
-                                                            const float* __restrict__ g, int64_t ldg, int gcol0, float out_scale,
-                                                            float* __restrict__ gfreq, float* __restrict__ gkey, int64_t ldk) {
-  constexpr int CAP = M * kWave;
-  __shared__ unsigned long long xb[NW * CAP];
-  __shared__ float red[NW];
-  const int pbeg = bin_start[bin_lo], nrows = bin_start[bin_hi + 1] - pbeg;
-  const int lane = lane_id(), w = wave_id();
-  const int xcd = blockIdx.x & 7;
-  for (int64_t vb = blockIdx.x;; vb += gridDim.x) {
-    const int64_t i = vb >> 3;
-    const int64_t rl = i / S;
-    const int k = (int)(i - rl * S);
-    const int64_t r = rl * 8 + xcd;
-    if (r >= nrows) return;
-    const int node = perm[pbeg + r];
-    const int start = rowptr[node];
-    const int D = rowptr[node + 1] - start;
-    if (D < dmin || D > dmax) continue;          // instantiations of different widths share the bins
-    const int32_t* colrow = col + start;
-    WaveLine64<M> ln;
-    {
-      int c[M];
-#pragma unroll
-      for (int j = 0; j < M; ++j) c[j] = colrow[min(w * CAP + j * kWave + lane, D - 1)];
-#pragma unroll
-      for (int j = 0; j < M; ++j) {
-        const int t = w * CAP + j * kWave + lane;
-        const float key = Xp[(int64_t)c[j] * ldp + k];
-        ln.e[j] = pack_key_index(t < D ? key : __builtin_inff(), t);
-      }
-    }
-    ln.sort();
-#pragma unroll
-    for (int size = 2; size <= NW; size <<= 1) {
-      wave_exchange64<M>(ln, xb, w, lane, w ^ (size - 1), true, (w & (size >> 1)) == 0);
-      for (int st = size >> 2; st >= 1; st >>= 1) wave_exchange64<M>(ln, xb, w, lane, w ^ st, false, (w & st) == 0);
-      ln.merge_chunk();
-    }
-    const double xi = (double)freqs[k];
-    const float gi = out_scale * g[(int64_t)node * ldg + gcol0 + k];
-    float* gk = gkey + (int64_t)start * ldk + k;
-    float gf = walk_line<M, false>(
-        ln, w * CAP + lane * M, D, D, xi, 1.0 / (double)D, gi, 0.0, [](int) { return 0.f; }, [&](int id, float v) { gk[(int64_t)id * ldk] = v; });
-    gf = wave_sum_b(gf);
-    if (lane == 0) red[w] = gf;
-    __syncthreads();
-    if (threadIdx.x == 0 && gfreq) {
-      float tot = 0.f;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) tot += red[q];
-      atomicAdd(gfreq + k, tot);
-    }
-    __syncthreads();
-  }
-}
-
-template <int NW, int M>
-static int launch_hub_bwd(const fsw_embed_args& a, int bin_lo, int bin_hi, int dmin, int dmax, int64_t rows_upper, const float* g, int64_t ldg,
-                          float* gfreq, float* gkey, int64_t ldk, hipStream_t stream) {
-  rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
-  if (rows_upper <= 0) return 0;
-  const int64_t nvirtual = ceil_div(rows_upper, 8) * a.S * 8;
-  k_embed_hub_bwd<NW, M><<<(unsigned)std::min<int64_t>(nvirtual, 1ll << 20), NW * kWave, 0, stream>>>(
-      a.rowptr, a.col, a.perm, a.bin_start, bin_lo, bin_hi, dmin, dmax, a.Xp, a.ldp, a.S, a.freqs, g, ldg, a.has_mass, a.out_scale, gfreq, gkey, ldk);
-  FSW_LAUNCH_CHECK();
-  return 0;
-}
-
 // ---- rows above FSW_LDS_MAX_DEG ------------------------------------------------------------------------------------------
 // fences below: workgroup scope orders a wave's scratch stores before its own later loads (same CU, same L1; see embed_wsort.hip)
 constexpr int kSweepDepthB = 4;
@@ -473,13 +374,13 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
                                                                 float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
                                                                 const float* __restrict__ efeat, const float* __restrict__ Ve,
                                                                 int64_t ldve, int d_edge, float* __restrict__ gkey, int64_t ldk,
-                                                                char* __restrict__ scratch, int64_t wave_bytes, int first_bin) {
+                                                                char* __restrict__ scratch, int64_t wave_bytes) {
   constexpr int CAP = M * kWave;
   const int lane = lane_id();
   const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
   unsigned long long* se = reinterpret_cast<unsigned long long*>(scratch + (int64_t)gw * wave_bytes);   // packed (key, index) words
   float* sc = reinterpret_cast<float*>(se + wave_bytes / 12);                                           // contributions, element order
-  const int pbeg = bin_start[first_bin], pend = bin_start[FSW_BIN_GLOBAL + 1];   // every row from bin first_bin on (>= FSW_BIN_HUB0)
+  const int pbeg = bin_start[FSW_BIN_HUB0], pend = bin_start[FSW_BIN_GLOBAL + 1];   // every row above FSW_LDS_MAX_DEG
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
     const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
@@ -602,25 +503,14 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
     nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 4) * 4) & ~(int64_t)3;
     FSW_REQUIRE(nwaves >= 4, "fsw_embed_backward: scratch buffer too small (need fsw_embed_scratch_bytes(max_degree))");
     char* scratch = reinterpret_cast<char*>(a.scratch);
-    int first_bin = FSW_BIN_HUB0;
-    // unit weights with stored key gradients: 2049 .. 16384 neighbours on the multi-wavefront lines (k_embed_hub_bwd: 4 / 8 / 16
-    // wavefronts x 1024 elements); what is above stays on the scratch lines
-    if (unit && gkey && !a.efeat && !getenv("FSW_BWD_QUAD_OFF")) {
-      const int64_t md = a.max_degree;
-      if ((rc = launch_hub_bwd<4, 16>(a, FSW_BIN_HUB0, FSW_BIN_HUB0, 2049, 4096, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
-      if (md > 4096 && (rc = launch_hub_bwd<8, 16>(a, FSW_BIN_HUB0 + 1, FSW_BIN_HUB0 + 1, 4097, 8192, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
-      if (md > 8192 && (rc = launch_hub_bwd<16, 16>(a, FSW_BIN_HUB0 + 2, FSW_BIN_HUB0 + 2, 8193, 16384, rows_upper, g, ldg, gfreq, gkey, ldk, stream))) return rc;
-      first_bin = FSW_BIN_HUB0 + 3;
-      if (bin_rows_or(a, first_bin, FSW_BIN_GLOBAL, 1) <= 0) return 0;
-    }
     if (unit)
       k_embed_wsort_global_bwd<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
           a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
-          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes, first_bin);
+          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
     else
       k_embed_wsort_global_bwd<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
           a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
-          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes, first_bin);
+          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
     FSW_LAUNCH_CHECK();
     return 0;
   }
