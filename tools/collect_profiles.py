@@ -35,6 +35,21 @@ head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], captu
 t = json.load(open(latest))
 t["source"] = {"git_head": head, "captured": datetime.datetime.now().isoformat(timespec="seconds"),
                "how": "tools/refresh_profiles.sh %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py" % tag}
+# the stand-alone segmented scan has its own PMC passes (2.56e8 elements per launch)
+try:
+    import csv as _csv
+
+    def _mean(path, needle):
+        v = [float(r["Counter_Value"]) for r in _csv.DictReader(open(path)) if needle in r["Kernel_Name"]]
+        return sum(v) / len(v)
+    sf = glob.glob(os.path.join(src, "seg_pmc_fetch", "**", "*counter_collection.csv"), recursive=True)[0]
+    sw = glob.glob(os.path.join(src, "seg_pmc_write", "**", "*counter_collection.csv"), recursive=True)[0]
+    f_, w_ = _mean(sf, "k_segscan_chained") * 1024.0, _mean(sw, "k_segscan_chained") * 1024.0
+    t["k_segscan_chained_hbm_bytes_per_launch"] = 2 * f_ + w_
+    t["k_segscan_chained_elements_per_launch"] = 256000000
+    t["k_segscan_chained_algorithmic_bytes_per_launch"] = 16.0 * 256000000
+except (IndexError, ZeroDivisionError, KeyError):
+    print("no segcumsum PMC passes in", src)
 json.dump(t, open(latest, "w"), indent=1)
 shutil.copy(latest, os.path.join(dst, name + "_pmc_traffic.json"))
 for sub, out in (("rmat22", "_rmat22_forward_kernel_stats.csv"), ("segcumsum", "_segcumsum_kernel_stats.csv"),

@@ -18,6 +18,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 grep "inference forward" "$out/rmat22.log"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/segcumsum" -- python3 "$root/tools/bench_segcumsum.py" --elems 2560000000 --reps 3 --no-check > "$out/segcumsum.log" 2>&1 || { echo "segcumsum run failed"; tail -5 "$out/segcumsum.log"; exit 1; }
 grep "^{" "$out/segcumsum.log" | tail -1 > "$out/segcumsum.json"; cat "$out/segcumsum.json"
+# HBM traffic of the scan (separate PMC passes, kernel trace only): 2.56e8 elements
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/seg_pmc_fetch" -- python3 "$root/tools/bench_segcumsum.py" --elems 256000000 --reps 2 --no-check > "$out/seg_pmc_fetch.log" 2>&1 || echo "segcumsum fetch pass failed"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/seg_pmc_write" -- python3 "$root/tools/bench_segcumsum.py" --elems 256000000 --reps 2 --no-check > "$out/seg_pmc_write.log" 2>&1 || echo "segcumsum write pass failed"
 timeout -k 10 300 python3 "$root/tools/exp_skew.py" > "$out/skew_rmat20.log" 2>/dev/null; cat "$out/skew_rmat20.log"
 timeout -k 10 300 python3 "$root/tools/exp_slice_shard.py" --worlds 4,8 > "$out/slice_shard_consumer.log" 2>/dev/null; cat "$out/slice_shard_consumer.log"
 timeout -k 10 300 python3 "$root/tools/exp_slice_shard.py" --worlds 4,8 --mode exchange > "$out/slice_shard_exchange.log" 2>/dev/null; cat "$out/slice_shard_exchange.log"
