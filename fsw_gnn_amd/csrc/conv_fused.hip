@@ -41,7 +41,7 @@ constexpr int kLdT = 132;   // LDS row stride of the staged output tile (Hout <=
 #define FSW_FUSED_PREFETCH 8
 #endif
 #ifndef FSW_FUSED_NARROW_WAVES
-#define FSW_FUSED_NARROW_WAVES 4   // waves per SIMD the narrow-block variant (RPW = 2) is compiled for; measured: tools/r3_run10.sh
+#define FSW_FUSED_NARROW_WAVES 4   // waves per SIMD the narrow-block variant (RPW = 2) is compiled for; measured: tools/exp_r3_narrow_occupancy.sh
 #endif
 
 struct FusedArgs {

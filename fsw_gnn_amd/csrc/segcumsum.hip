@@ -189,7 +189,7 @@ struct SegTile {
 };
 
 #ifndef FSW_SEG_MINWAVES
-#define FSW_SEG_MINWAVES 1   // waves per SIMD the kernel is compiled for (register cap); measured: tools/r3_run9.sh
+#define FSW_SEG_MINWAVES 1   // waves per SIMD the kernel is compiled for (register cap); measured: tools/exp_r3_segscan_registers.sh
 #endif
 template <class V, class I, bool REV, bool VEC>
 __global__ void __launch_bounds__(kSegThreads, FSW_SEG_MINWAVES) k_segscan_chained(const V* __restrict__ values, V* __restrict__ out,
