@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 3: exchange form + halo segscan tests, segscan variants, hub ablations, slice-shard compute, bench lines
+# Variants first (build container):  tools/build_variant.sh hub_nogather embed_hub_0 "-DFSW_HUB_ABL=1"; tools/build_variant.sh hub_gatheronly
+#   embed_hub_0 "-DFSW_HUB_ABL=14"; tools/build_variant.sh hub_noreadout embed_hub_0 "-DFSW_HUB_ABL=8"; seg_* as in the segscan scripts
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/r3d

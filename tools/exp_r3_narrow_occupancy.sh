@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 GPU call 10: narrow fused kernel at higher occupancy (6 / 8 waves per SIMD), slice-parallel tests
+# Variants first (build container):  for w in 6 8; do tools/build_variant.sh fused_nw$w conv_fused "-DFSW_FUSED_NARROW_WAVES=$w"; done
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/r3k

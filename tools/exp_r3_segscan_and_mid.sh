@@ -1,5 +1,8 @@
 #!/bin/bash
 # round-3 GPU call 2: full GPU test suite on the new kernels, mid-class A/B, config-5 forward profile, segcumsum ablations
+# Variants first (build container):  for a in 1 3 7; do tools/build_variant.sh seg_abl$a segcumsum "-DFSW_SEG_ABL=$a"; done;
+#   tools/build_variant.sh seg_wg4np segcumsum "-DFSW_SEG_PREFETCH=0 -DFSW_SEG_WG_PER_CU=4"; tools/build_variant.sh midll2 embed_hub_0 "-DFSW_MIDSPLIT_LL=2";
+#   tools/build_variant.sh midll8 embed_hub_0 "-DFSW_MIDSPLIT_LL=8"   (FSW_MID_SPLIT=1 selects the split kernels at run time)
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/r3c

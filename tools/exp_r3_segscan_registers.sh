@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 GPU call 9: segscan register-cap variants (workgroups per CU), segcumsum tests, d = 256 fused path check (yin by node)
+# Variants first (build container):  for w in 4 5 6; do tools/build_variant.sh seg_mw$w segcumsum "-DFSW_SEG_MINWAVES=$w"; done
 set -o pipefail
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/r3j
