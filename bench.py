@@ -14,12 +14,14 @@ A step is ONE full FSW_conv.forward(x, edge_index): CSR build from the int64 edg
 the reference, fsw_conv.py:352 -- nothing is cached), fp32-MFMA projection, fused neighbourhood sort / cumulative
 sum / Fourier readout, concat with the vertex features and the Linear layer.  Inputs are resident in HBM before
 the timed region.  With N > 1 the SLICE axis is sharded over the ranks (BASELINE north_star; 256 / N slices each, total
-work fixed -> strong scaling): by default the sharded-consumer form of fsw_gnn_amd/dist.py (every rank multiplies its
-slice block by its columns of the first Linear layer inside the fused kernel, the n x 128 partial sums are
-reduce-scattered, finished rows all-gathered, node-range chunks pipelined); --mode gather runs the contracted
-all-gather of the embedding instead.  The line then also carries compute_ms (the same step with the collectives
-replaced by local copies), collective_ms / collective_GBps (the step's collectives alone on same-size buffers) and
-bytes per rank.  --shard nodes (recipient-row sharding, not the contracted partition) stays behind its flag.
+work fixed -> strong scaling) and EVERY form of fsw_gnn_amd/dist.py is timed over the same W + K steps: 'gather' (north_star's
+all-gather of the embedding), 'consumer' (every rank multiplies its slice block by its columns of the first Linear layer inside
+the fused kernel, the n x 128 partial sums are reduce-scattered, finished rows all-gathered) and 'exchange' (one all-to-all of
+slice blocks to the row owners); node-range chunks pipelined; the headline is the fastest form that leaves the full output on
+every rank.  Each form carries compute_ms (the same step with the collectives replaced by local copies), collective_ms /
+collective_GBps (the form's collectives alone on same-size buffers) and
+bytes per rank.  Recipient-row sharding (not the contracted partition) is timed in the same run as `other_partitions` and is
+never the headline; --shard nodes makes it the only thing that runs.
 
 The JSON line also carries
   roofline     the dominant kernel (k_conv_fused_unit; k_embed_reg_unit with --no-fuse) timed alone, HIP events on the launch stream:
@@ -68,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-segcumsum", action="store_true", help="skip the stand-alone segmented-cumsum throughput leg")
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling leg (128 slices per GPU, BASELINE config 4's shape)")
+    ap.add_argument("--no-other-partitions", action="store_true",
+                    help="N > 1: skip the recipient-row sharded leg (reported beside the slice-axis forms, never the headline)")
     ap.add_argument("--cpu-slices", type=int, default=256)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="force the unfused kernels (embedding written to HBM, torch Linear)")
@@ -477,6 +481,47 @@ def weak_scaling_leg(args, x, ei, e_coalesced, dev, world, rank):
             "bytes_received_per_rank": st.get("bytes_received_per_rank")}
 
 
+def recipient_rows_leg(args, x, ei, e_coalesced, S, dev, world, rank):
+    """Outside north_star's slice-axis contract, for comparison in the same record: the RECIPIENT rows sharded over the ranks
+    (FSW_conv.enable_node_parallel: projection replicated, CSR + fused kernel on n / N rows, ONE all-gather of the output
+    rows).  Same W + K steps and the same max-over-ranks clock as the forms above; compute_ms = the step without the collective."""
+    from fsw_gnn_amd import FSW_conv
+    ok, err, conv = True, None, None
+    try:
+        torch.manual_seed(4321)
+        conv = FSW_conv(D_FEAT, OUT_CH, embed_dim=S + 1, device=dev)
+        conv.enable_node_parallel(None)
+    except Exception as e:   # noqa: BLE001
+        ok, err = False, "%s: %s" % (type(e).__name__, e)
+    if not all_ranks_ok(ok, dev, world):
+        return {"error": err or "another rank failed to set the leg up"}
+
+    def step():
+        with torch.no_grad():
+            return conv(x, ei)
+
+    elapsed, y = timed_steps(step, args.warmup, args.steps, dev, world)
+    n, H = x.shape[0], conv.mlp[0].out_features
+    per = -(-n // world)
+    out = {"partition": "recipient rows (not the contracted slice-axis shard)", "collective": "all_gather", "output": "replicated",
+           "ms_per_step": elapsed / args.steps * 1e3, "value": float(e_coalesced) * S * args.steps / elapsed,
+           "bytes_sent_per_rank": 4 * per * H * (world - 1), "bytes_received_per_rank": 4 * per * H * (world - 1),
+           "finite": bool(torch.isfinite(y).all())}
+    cms, err = 0.0, None
+    try:
+        with torch.no_grad():
+            cms = timed_ms(lambda: conv._forward_node_parallel(x, ei, _emulate=(rank, world)), max(3, args.kernel_reps // 4), dev)
+    except Exception as e:   # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    if all_ranks_ok(err is None, dev, world):
+        t = torch.tensor([cms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["compute_ms"] = float(t)
+    else:
+        out["compute_ms_error"] = err or "another rank failed"
+    return out
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -625,6 +670,8 @@ def main():
                 result["roofline"] = roof
         except Exception as e:   # noqa: BLE001
             result["extras_error"] = "%s: %s" % (type(e).__name__, e)
+    if world > 1 and not node_parallel and not args.no_fuse and not args.no_other_partitions:
+        result["other_partitions"] = {"recipient_rows": recipient_rows_leg(args, x, ei, e_coalesced, S, dev, world, rank)}
     if not args.no_weak and not node_parallel and args.slices == N_SLICES:
         del conv
         torch.cuda.empty_cache()

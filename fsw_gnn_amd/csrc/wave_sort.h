@@ -91,14 +91,19 @@ struct WaveLine {
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      if constexpr (WEIGHTED) {
-        bool take = lower ? (ok[j] < k[j]) : (ok[j] > k[j]);   // ties: both lanes keep their own element
-        if constexpr (TIEBREAK) {
-          const int oi = __float_as_int(ow[j]), mi = __float_as_int(w[j]);
-          take = take || (ok[j] == k[j] && (lower ? oi < mi : oi > mi));
-        }
+      if constexpr (WEIGHTED && TIEBREAK) {
+        bool take = lower ? (ok[j] < k[j]) : (ok[j] > k[j]);
+        const int oi = __float_as_int(ow[j]), mi = __float_as_int(w[j]);
+        take = take || (ok[j] == k[j] && (lower ? oi < mi : oi > mi));
         k[j] = take ? ok[j] : k[j];
         w[j] = take ? ow[j] : w[j];
+      } else if constexpr (WEIGHTED) {
+        // the key as in the unit line (one v_med3); the payload follows the key: it moves exactly when the kept key is not this
+        // lane's own (ties: both lanes keep their own element).  Three instructions per element next to the two lane moves --
+        // `lower ? ok < k : ok > k` compiled to two compares plus selects of the compare results per element
+        const float kn = minmax_by_limit(k[j], ok[j], lim);
+        w[j] = kn != k[j] ? ow[j] : w[j];
+        k[j] = kn;
       } else {
         k[j] = minmax_by_limit(k[j], ok[j], lim);
       }
@@ -210,7 +215,7 @@ struct WaveLine64 {
     for (int j = 0; j < M; ++j) o[j] = xor_lane64<MASK>(e[JREV ? M - 1 - j : j]);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const bool take = lower ? (o[j] < e[j]) : (o[j] > e[j]);
+      const bool take = (o[j] < e[j]) == lower;   // the words of a line are distinct (element index in the low half): one compare
       e[j] = take ? o[j] : e[j];
     }
   }
