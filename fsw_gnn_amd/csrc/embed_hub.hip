@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, M >= 24 ? 2 : 3) k
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ wgt, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float tau, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
-    int has_mass, int mass_fn, float mass_scale) {
+    int has_mass, int mass_fn, float mass_scale, int dlo, int dhi) {
   constexpr int CAP = M * kWave;
   constexpr int LPB = NW == 1 ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) float xsm[];   // NW > 1: keys [NW][CAP] | weights [NW][CAP]
@@ -966,6 +966,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, M >= 24 ? 2 : 3) k
     const int node = perm[pbeg + r];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
+    if (D <= dlo || D > dhi) continue;                       // another capacity class of this bin (launch_embed_hub_weighted_*)
     const int Dtot = D + 1;                                  // with the pad element; Dtot <= NW * CAP by the class bounds
 
     // gather (striped: element t0 + j * 64 + lane), total mass, pad element
@@ -1063,43 +1064,65 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, M >= 24 ? 2 : 3) k
   }
 }
 
+// rows of the bins bin_lo .. bin_hi with dlo < degree <= dhi (the pad element must fit: dhi + 1 <= NW * M * 64)
 template <int NW, int M>
-static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, hipStream_t stream) {
+static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t rows_upper, hipStream_t stream, int dlo = 0,
+                        int dhi = NW * M * kWave - 1) {
   constexpr int LPB = NW == 1 ? 4 : 1;
+  static_assert(NW * M * kWave >= 2, "line capacity");
+  dhi = std::min(dhi, NW * M * kWave - 1);
   rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
-  if (rows_upper <= 0) return 0;
+  if (rows_upper <= 0 || dlo >= dhi || (a.max_degree > 0 && a.max_degree <= dlo)) return 0;
   const size_t lds = NW > 1 ? sizeof(float) * 2 * NW * M * kWave : 0;
   if (lds > 64 * 1024) FSW_SET_MAX_LDS_ONCE((&k_embed_hub_w<NW, M>), lds);
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
   k_embed_hub_w<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, lds, stream>>>(
       a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, a.Xp, a.ldp, a.S, a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale,
-      a.has_mass, a.mass_fn, a.mass_scale);
+      a.has_mass, a.mass_fn, a.mass_scale, dlo, dhi);
   FSW_LAUNCH_CHECK();
   return 0;
 }
 
+#define FSW_HW(NW, M, LO, HI, DLO, DHI) \
+  if ((rc = launch_hub_w<NW, M>(a, LO, HI, rows_upper, stream, DLO, DHI))) return rc
 #if FSW_HUB_PART == 1
 // general weights without edge features: rows of FSW_MID_MAX_DEG_WEIGHTED < degree <= 4096 (bins bin_lo .. FSW_BIN_HUB0).
 // bin_lo: the first mid bin above FSW_MID_MAX_DEG_WEIGHTED.  lds_rows / hub_rows bound the rows of the two ranges.
 int launch_embed_hub_weighted_lds(const fsw_embed_args& a, int bin_lo, int64_t rows_upper, hipStream_t stream) {
-  // D + 1 elements: a class of up to 2^k neighbours needs 2^k + 1 slots -- 3/4 of the next power of two (6 / 12 / 24 keys per lane)
+  // A line holds D + 1 elements, and a bitonic line costs its CAPACITY, not its fill: every bin is split over the capacities
+  // 64 * {3, 4, 6, 8, 12, 16, 24} (x 2 wavefronts) by a degree window inside the kernel -- a row of 300 neighbours runs on 384
+  // wires instead of 768, the one row of exactly 512 (513 elements) on 768.  Rows outside a launch's window cost two loads.
   int rc;
-  if (bin_lo < FSW_BIN_LDS0 && (rc = launch_hub_w<1, 6>(a, bin_lo, FSW_BIN_LDS0 - 1, rows_upper, stream))) return rc;    // ..256 (+1) in 384
-  if ((rc = launch_hub_w<1, 12>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, stream))) return rc;                          // ..512 in 768
-  if ((rc = launch_hub_w<1, 24>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;                  // ..1024 in 1536
-  if ((rc = launch_hub_w<2, 24>(a, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, rows_upper, stream))) return rc;                  // ..2048 in 3072
+  constexpr int B160 = FSW_BIN_LDS0 - 3, B192 = FSW_BIN_LDS0 - 2, B256 = FSW_BIN_LDS0 - 1;   // mid bins ..160, ..192, ..256
+  if (bin_lo <= B160) FSW_HW(1, 3, std::max(bin_lo, B160), B160, 0, 191);
+  if (bin_lo <= B256) FSW_HW(1, 4, std::max(bin_lo, B192), B256, 0, 255);
+  if (bin_lo <= B256) FSW_HW(1, 6, B256, B256, 255, 383);
+  FSW_HW(1, 6, FSW_BIN_LDS0, FSW_BIN_LDS0, 0, 383);               // 257 .. 512
+  FSW_HW(1, 8, FSW_BIN_LDS0, FSW_BIN_LDS0, 383, 511);
+  FSW_HW(1, 12, FSW_BIN_LDS0, FSW_BIN_LDS0, 511, 767);
+  FSW_HW(1, 12, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, 0, 767);      // 513 .. 1024
+  FSW_HW(1, 16, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, 767, 1023);
+  FSW_HW(1, 24, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, 1023, 1535);
+  FSW_HW(1, 24, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, 0, 1535);     // 1025 .. 2048
+  FSW_HW(2, 16, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, 1535, 2047);
+  FSW_HW(2, 24, FSW_BIN_LDS0 + 2, FSW_BIN_LDS0 + 2, 2047, 3071);
   return 0;
 }
 #elif FSW_HUB_PART == 2
+// general weights, 2049 .. kHubWMaxDeg (fsw_common.h) neighbours: two and four wavefronts per line.  Above, the scratch-line kernel of
+// embed_wsort.hip stays: sixteen wavefronts x 12 keys (or eight x 24) per line measured 124 (159) ms on the RMAT graph's class
+// 4097..8192 against its 97 ms -- one workgroup per CU at 96 KB of exchange buffer does not cover the barrier-separated exchanges
 int launch_embed_hub_weighted_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   int rc;
-  // ..4096 in 6144.  Above, the scratch-line kernel of embed_wsort.hip stays: sixteen wavefronts x 12 keys (or eight x 24) per
-  // line measured 124 (159) ms on the RMAT graph's class 4097..8192 against its 97 ms -- one workgroup per CU at 96 KB of
-  // exchange buffer does not cover the barrier-separated exchanges
-  if ((rc = launch_hub_w<4, 24>(a, FSW_BIN_HUB0, FSW_BIN_HUB0, rows_upper, stream))) return rc;
+  FSW_HW(2, 24, FSW_BIN_HUB0, FSW_BIN_HUB0, 0, 3071);             // 2049 .. 4096
+  FSW_HW(4, 16, FSW_BIN_HUB0, FSW_BIN_HUB0, 3071, 4095);
+  FSW_HW(4, 24, FSW_BIN_HUB0, FSW_BIN_HUB0, 4095, 6143);
+  FSW_HW(4, 24, FSW_BIN_HUB0 + 1, FSW_BIN_HUB0 + 1, 0, 6143);     // 4097 .. 8191 (8192 itself: scratch-line kernel)
+  FSW_HW(4, 32, FSW_BIN_HUB0 + 1, FSW_BIN_HUB0 + 1, 6143, kHubWMaxDeg);
   return 0;
 }
+#undef FSW_HW
 
 #else
 // unit weights, tau <= 1: rows of the four hub bins.  rows_upper bounds the rows above FSW_LDS_MAX_DEG (the per-bin counts

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
                                                             float out_scale, int has_mass, int mass_fn, float mass_scale,
                                                             const float* __restrict__ efeat, const float* __restrict__ Ve,
                                                             int64_t ldve, int d_edge, char* __restrict__ scratch, int64_t wave_bytes,
-                                                            int bin_lo) {
+                                                            int bin_lo, int bin_hi, int dlo) {
   constexpr int CAP = M * kWave;
   const int lane = lane_id();
   // lines are numbered (row, slice) with the slice fastest; the workgroups of one XCD (blockIdx.x % 8 under round-robin
@@ -282,15 +282,16 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
   const int gw = blk * 4 + wave_id(), nwaves = gridDim.x * 4;
   float* sk = reinterpret_cast<float*>(scratch + (int64_t)gw * wave_bytes);
   float* sw = sk + (wave_bytes >> 3);                   // second half of the wave's region (weighted only)
-  const int pbeg = bin_start[bin_lo], pend = bin_start[FSW_BIN_GLOBAL + 1];
+  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
     const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
     const int node = perm[p];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
+    if (D <= dlo) continue;                             // done by k_embed_hub_w (launch_embed_global)
     const int Dtot = WEIGHTED ? D + 1 : D;
-    const int Dp = (int)pow2ceil((uint32_t)Dtot);       // >= 2 CAP: D > FSW_LDS_MAX_DEG = CAP
+    const int Dp = (int)pow2ceil((uint32_t)Dtot);       // >= 2 CAP: D > FSW_LDS_MAX_DEG = CAP; <= wave_bytes / 8 by the bin's bound
     double m = (double)D;
     float padw = 0.f;
     if constexpr (WEIGHTED) {
@@ -427,27 +428,35 @@ int launch_embed_hub_weighted_hub(const fsw_embed_args& a, int64_t rows_upper, h
 // general weights: every row above FSW_LDS_MAX_DEG (unit weights with tau <= 1 take embed_hub.hip's kernels)
 int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
   if (rows_upper <= 0) return 0;
-  // without edge features the rows of up to 4096 neighbours keep their line in registers (embed_hub.hip: k_embed_hub_w)
-  int first_bin = FSW_BIN_HUB0;
+  // without edge features the rows of up to kHubWMaxDeg neighbours keep their line in registers (embed_hub.hip: k_embed_hub_w)
+  int first_bin = FSW_BIN_HUB0, dlo = 0;
   if (FSW_WEIGHTED_HUB && !a.efeat) {
     if (int rc = launch_embed_hub_weighted_hub(a, rows_upper, stream)) return rc;
-    first_bin = FSW_BIN_HUB0 + 1;
-    if (a.max_degree > 0 && a.max_degree <= 4096) return 0;
+    first_bin = FSW_BIN_HUB0 + 1;      // its rows of exactly 8192 neighbours (8193 elements) are all that is left of this bin
+    dlo = kHubWMaxDeg;
+    if (a.max_degree > 0 && a.max_degree <= kHubWMaxDeg) return 0;
     if (bin_rows_or(a, first_bin, FSW_BIN_GLOBAL, 1) <= 0) return 0;
   }
   FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
   FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
-  const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
-  const int64_t wave_bytes = Dp * 8;
-  int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
-  nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 32) * 32);
-  nwaves = nwaves >= 32 ? (nwaves & ~(int64_t)31) : (nwaves & ~(int64_t)3);   // whole workgroups; a multiple of 8 of them when possible
-  FSW_REQUIRE(nwaves >= 4, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
   char* scratch = reinterpret_cast<char*>(a.scratch);
-  k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
-      a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
-      first_bin);
-  FSW_LAUNCH_CHECK();
+  // One launch per degree bin, each with the scratch line its OWN longest row needs: sized by the graph's longest row, a single
+  // 150 000-neighbour hub left 680 wavefronts (two thirds of one per SIMD) for every row above 4096 neighbours.
+  for (int bin = first_bin; bin <= FSW_BIN_GLOBAL; ++bin) {
+    const int64_t rows = bin_rows_or(a, bin, bin, rows_upper);
+    if (rows <= 0) continue;
+    const int64_t bin_max = bin == FSW_BIN_GLOBAL ? a.max_degree : std::min<int64_t>(a.max_degree, (int64_t)4096 << (bin - FSW_BIN_HUB0));
+    if (bin > FSW_BIN_HUB0 && bin_max <= ((int64_t)2048 << (bin - FSW_BIN_HUB0))) continue;   // no row of the graph reaches this bin
+    const int64_t wave_bytes = (int64_t)pow2ceil((uint32_t)(bin_max + 1)) * 8;
+    int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
+    nwaves = std::min<int64_t>(nwaves, ceil_div(rows * a.S, 32) * 32);
+    nwaves = nwaves >= 32 ? (nwaves & ~(int64_t)31) : (nwaves & ~(int64_t)3);   // whole workgroups; a multiple of 8 of them when possible
+    FSW_REQUIRE(nwaves >= 4, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
+    k_embed_wsort_global<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S,
+        a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale, a.efeat, a.Ve, a.ldve, a.d_edge, scratch, wave_bytes,
+        bin, bin, dlo);
+    FSW_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -374,13 +374,13 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
                                                                 float* __restrict__ gXp, int64_t ldgp, float* __restrict__ gfreq,
                                                                 const float* __restrict__ efeat, const float* __restrict__ Ve,
                                                                 int64_t ldve, int d_edge, float* __restrict__ gkey, int64_t ldk,
-                                                                char* __restrict__ scratch, int64_t wave_bytes) {
+                                                                char* __restrict__ scratch, int64_t wave_bytes, int bin_lo, int bin_hi) {
   constexpr int CAP = M * kWave;
   const int lane = lane_id();
   const int gw = blockIdx.x * 4 + wave_id(), nwaves = gridDim.x * 4;
   unsigned long long* se = reinterpret_cast<unsigned long long*>(scratch + (int64_t)gw * wave_bytes);   // packed (key, index) words
   float* sc = reinterpret_cast<float*>(se + wave_bytes / 12);                                           // contributions, element order
-  const int pbeg = bin_start[FSW_BIN_HUB0], pend = bin_start[FSW_BIN_GLOBAL + 1];   // every row above FSW_LDS_MAX_DEG
+  const int pbeg = bin_start[bin_lo], pend = bin_start[bin_hi + 1];   // rows above FSW_LDS_MAX_DEG, one launch per degree bin
   const int64_t nlines = (int64_t)(pend - pbeg) * S;
   for (int64_t ln_id = gw; ln_id < nlines; ln_id += nwaves) {
     const int p = pbeg + (int)(ln_id / S), k = (int)(ln_id % S);
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global_bwd(const int32_t* _
 // room for up to 2048 resident waves, capped at 2 GiB -- fewer waves then share the lines of a very long row.
 size_t embed_global_scratch_bytes(int64_t max_degree) {
   const size_t wave_bytes = (size_t)pow2ceil((uint32_t)(max_degree + 1)) * 12;
-  const size_t cap = (size_t)2 << 30;
+  const size_t cap = (size_t)2 << 30;   // (6 GB = 2048 wavefronts on a 150 000-neighbour line measured slower than 680: 70.7 vs 61.6 ms)
   size_t waves = std::min<size_t>(2048, cap / wave_bytes);
   waves = std::max<size_t>(waves & ~(size_t)3, 4);
   return waves * wave_bytes;
@@ -497,21 +497,27 @@ int launch_embed_long_bwd(const fsw_embed_args& a, bool global, int64_t rows_upp
   int rc;
   if (global) {
     FSW_REQUIRE(a.scratch && a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_backward: rows above FSW_LDS_MAX_DEG need the scratch buffer and max_degree");
-    const int64_t Dp = (int64_t)pow2ceil((uint32_t)(a.max_degree + 1));
-    const int64_t wave_bytes = Dp * 12;
-    int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
-    nwaves = std::min<int64_t>(nwaves, ceil_div(rows_upper * a.S, 4) * 4) & ~(int64_t)3;
-    FSW_REQUIRE(nwaves >= 4, "fsw_embed_backward: scratch buffer too small (need fsw_embed_scratch_bytes(max_degree))");
     char* scratch = reinterpret_cast<char*>(a.scratch);
-    if (unit)
-      k_embed_wsort_global_bwd<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
-          a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
-          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
-    else
-      k_embed_wsort_global_bwd<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
-          a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
-          gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes);
-    FSW_LAUNCH_CHECK();
+    // one launch per degree bin, the scratch line sized by the bin's own longest row (see launch_embed_global, embed_wsort.hip)
+    for (int bin = FSW_BIN_HUB0; bin <= FSW_BIN_GLOBAL; ++bin) {
+      const int64_t rows = bin_rows_or(a, bin, bin, rows_upper);
+      if (rows <= 0) continue;
+      const int64_t bin_max = bin == FSW_BIN_GLOBAL ? a.max_degree : std::min<int64_t>(a.max_degree, (int64_t)4096 << (bin - FSW_BIN_HUB0));
+      if (bin > FSW_BIN_HUB0 && bin_max <= ((int64_t)2048 << (bin - FSW_BIN_HUB0))) continue;   // no row of the graph reaches this bin
+      const int64_t wave_bytes = (int64_t)pow2ceil((uint32_t)(bin_max + 1)) * 12;
+      int64_t nwaves = std::min<int64_t>((int64_t)a.scratch_bytes / wave_bytes, 2048);
+      nwaves = std::min<int64_t>(nwaves, ceil_div(rows * a.S, 4) * 4) & ~(int64_t)3;
+      FSW_REQUIRE(nwaves >= 4, "fsw_embed_backward: scratch buffer too small (need fsw_embed_scratch_bytes(max_degree))");
+      if (unit)
+        k_embed_wsort_global_bwd<32, false><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
+            a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
+            gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes, bin, bin);
+      else
+        k_embed_wsort_global_bwd<32, true><<<(unsigned)(nwaves / 4), 256, 0, stream>>>(
+            a.rowptr, a.col, a.w, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.tau, g, ldg, a.has_mass, a.out_scale, gXp, ldgp,
+            gfreq, a.efeat, a.Ve, a.ldve, a.d_edge, gkey, ldk, scratch, wave_bytes, bin, bin);
+      FSW_LAUNCH_CHECK();
+    }
     return 0;
   }
 #define FSW_WB(M, WGT, LO, HI) \

@@ -66,6 +66,10 @@ __host__ __device__ inline int degree_bin(int deg) {
   return FSW_BIN_MID0 + i;
 }
 
+// general weights without edge features: rows of up to this many neighbours (+ the pad element = 8192 = four wavefronts x 32 keys per
+// lane) keep their (key, weight) line in registers (embed_hub.hip: k_embed_hub_w); above, the scratch-line kernel of embed_wsort.hip
+constexpr int kHubWMaxDeg = 8191;
+
 // rows of the degree bins lo .. hi when the caller passed the host copy of bin_start, `upper` (a bound) otherwise
 inline int64_t bin_rows_or(const fsw_embed_args& a, int lo, int hi, int64_t upper) {
   return a.bin_start_host ? (int64_t)a.bin_start_host[hi + 1] - a.bin_start_host[lo] : upper;

@@ -2,6 +2,7 @@
 
     python tools/exp_train_step.py            BASELINE config 3 (ER multigraph, every row on the <= 32 register path)
     python tools/exp_train_step.py --rmat 20  RMAT graph with 2^20 vertices and 10M edges (hubs up to 41 300 neighbours)
+    python tools/exp_train_step.py --rmat 22 --edges 64000000 --feat 256 --forward-only [--gcn]   BASELINE config 5's shape
 """
 import argparse, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +13,7 @@ ap.add_argument("--rmat", type=int, default=0)
 ap.add_argument("--forward-only", action="store_true")
 ap.add_argument("--edges", type=int, default=bench.N_EDGES)
 ap.add_argument("--feat", type=int, default=128)
+ap.add_argument("--gcn", action="store_true", help="edge_weighting='gcn': general edge weights (the (key, weight) kernels)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 n, E = bench.N_NODES, args.edges
@@ -22,7 +24,7 @@ if args.rmat:
 else:
     x, ei = bench.make_inputs(n, E, dev)
     assert args.feat == 128
-conv = FSW_conv(args.feat, 128, embed_dim=257, device=dev)
+conv = FSW_conv(args.feat, 128, embed_dim=257, device=dev, edge_weighting='gcn' if args.gcn else 'unit')
 with torch.no_grad():
     print("inference forward, %d nodes / %d edges / %d feat / 256 slices: %.2f ms (max in-degree %d)" % (
         n, E, args.feat, bench.timed_ms(lambda: conv(x, ei), 5, dev), int(torch.bincount(ei[1]).max())), flush=True)
