@@ -20,6 +20,7 @@
 #include "fsw_common.h"
 #include "sortnet.h"
 #include "wave_sort.h"
+#include "merge_path.h"
 
 namespace fsw {
 
@@ -535,7 +536,13 @@ __global__ void __launch_bounds__(kGiantNW* kWave, 4) k_embed_giant(const int32_
 }
 
 // unit weights, tau <= 1: the rows above FSW_HUB_MAX_DEG.  scratch: fsw_embed_scratch_bytes(max_degree).
+int launch_embed_mergepath(const fsw_embed_args& a, int bin_lo, int bin_hi, int dlo, int64_t rows_upper, hipStream_t stream);
 int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream) {
+  // FSW_GIANT_MERGEPATH=1: sorted blocks of 8192 + merge-path levels (k_embed_mergepath) instead of the block sweeps below.  Measured
+  // on the 64M-edge RMAT graph's 23 rows above 32768 neighbours: 6.33 ms against 6.07 ms here -- for bare keys the sweeps are cheap
+  // (one v_min / v_max per element) and a merge-path tile is a chain of dependent LDS reads at two wavefronts per SIMD; with a
+  // payload it is the other way round (k_embed_mergepath_w: 11.6 ms against 61.6 ms for the scratch-line kernel)
+  if (getenv("FSW_GIANT_MERGEPATH")) return launch_embed_mergepath(a, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL, FSW_HUB_MAX_DEG, rows_upper, stream);
   rows_upper = bin_rows_or(a, FSW_BIN_GLOBAL, FSW_BIN_GLOBAL, rows_upper);
   if (rows_upper <= 0 || (a.max_degree > 0 && a.max_degree <= FSW_HUB_MAX_DEG)) return 0;
   FSW_REQUIRE(a.max_degree > FSW_HUB_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_HUB_MAX_DEG");
@@ -549,6 +556,101 @@ int launch_embed_giant(const fsw_embed_args& a, int64_t rows_upper, hipStream_t 
   k_embed_giant<<<(unsigned)nwg, kGiantNW * kWave, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo,
                                                                 a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
                                                                 reinterpret_cast<float*>(a.scratch), line_floats);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- rows above FSW_HUB_MAX_DEG, unit weights: sorted blocks of 8192 keys + merge-path levels (merge_path.h) -------------------
+// Phase A is k_embed_hub<4, 32>'s line (four wavefronts x 32 keys per lane, sorted in registers, two bitonic levels through LDS)
+// for every block of 8192 neighbours, parked in the workgroup's scratch line; the levels above are one merge-path pass each, the
+// last one straight into the readout.  A 150 000-neighbour hub: 19 blocks, 5 passes (k_embed_giant: 10 blocks of 16384, 14 passes).
+struct MpKeys {
+  float k[kMpVT];
+};
+
+__global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
+                                                            int bin_lo, int bin_hi, int dlo, const float* __restrict__ Xp, int64_t ldp,
+                                                            int S, const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo,
+                                                            const float* __restrict__ bias, float out_scale, int has_mass, int mass_fn,
+                                                            float mass_scale, float* __restrict__ scratch, int64_t line_cap) {
+  constexpr int NW = 4, M = 32, CAP = M * kWave;
+  static_assert(NW * CAP == kMpBlk, "block = one workgroup's registers");
+  extern __shared__ __attribute__((aligned(16))) float xsm[];   // phase A: exchange buffer [NW][CAP]; levels: tile keys | tile boundaries
+  __shared__ float red[NW];
+  float* tk = xsm;
+  int* part = reinterpret_cast<int*>(xsm + kMpTileLds);
+  const int pbeg = bin_start[bin_lo], nrows = bin_start[bin_hi + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  float* k0 = scratch + (int64_t)blk * 2 * line_cap;
+  float* k1 = k0 + line_cap;
+  const int64_t nlines = (int64_t)nrows * S;
+  for (int64_t line = blk; line < nlines; line += gridDim.x) {
+    const int p = pbeg + (int)(line / S), k = (int)(line % S);
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    if (D <= dlo) continue;
+    const int nb = (D + kMpBlk - 1) / kMpBlk;
+    const float xif = freqs[k];
+    float acc = 0.f;
+    WaveLine<M, false> ln;
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+      gather_chunk<M>(ln, col + start, b * kMpBlk + w * CAP, D, Xp, ldp, k, lane);
+      ln.sort();
+      workgroup_merge_levels<NW, M>(ln, xsm, w, lane);
+      if (nb == 1) break;                                  // the whole line is in registers
+      float* dst = k0 + (int64_t)b * kMpBlk + w * CAP + lane * M;
+#pragma unroll
+      for (int j = 0; j < M; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(ln.k[j], ln.k[j + 1], ln.k[j + 2], ln.k[j + 3]);
+    }
+    if (nb == 1) {
+      acc = unit_readout<M>(ln, w * CAP + lane * M, D, xif);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+      merge_path_levels<false>(k0, k1, nullptr, nullptr, nb, tk, nullptr, part, [&](int r0, const float* ok, const float*) {
+        MpKeys t;
+#pragma unroll
+        for (int j = 0; j < kMpVT; ++j) t.k[j] = ok[j];
+        acc += unit_readout<kMpVT>(t, r0, D, xif);
+      });
+    }
+    acc = wave_sum_h(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot += red[q];
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+    __syncthreads();
+  }
+}
+
+// unit weights, tau <= 1: rows of the bins bin_lo .. bin_hi with more than dlo neighbours.  scratch: fsw_embed_scratch_bytes(max_degree).
+int launch_embed_mergepath(const fsw_embed_args& a, int bin_lo, int bin_hi, int dlo, int64_t rows_upper, hipStream_t stream) {
+  rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
+  if (rows_upper <= 0 || (a.max_degree > 0 && a.max_degree <= dlo)) return 0;
+  FSW_REQUIRE(a.max_degree > dlo, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
+  FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
+  FSW_REQUIRE(((uintptr_t)a.scratch & 15) == 0, "fsw_embed_f32: scratch must be 16-byte aligned");
+  const int64_t line_cap = ceil_div(a.max_degree, kMpBlk) * kMpBlk;
+  int64_t nwg = std::min<int64_t>((int64_t)(a.scratch_bytes / (size_t)(2 * line_cap * 4)), 512);   // two workgroups per CU
+  nwg = std::min<int64_t>(nwg, ceil_div(rows_upper * a.S, 8) * 8);
+  if (nwg >= 8) nwg &= ~(int64_t)7;
+  FSW_REQUIRE(nwg >= 1, "fsw_embed_f32: scratch buffer too small for rows above FSW_HUB_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
+  const size_t lds = sizeof(float) * 4 * 32 * kWave;      // phase A's exchange buffer; the tile + boundaries of the levels fit inside
+  static_assert(sizeof(float) * kMpTileLds + sizeof(int) * (kMpParts + 1) <= sizeof(float) * 4 * 32 * kWave, "LDS of the merge levels");
+  k_embed_mergepath<<<(unsigned)nwg, kMpNT, lds, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, bin_lo, bin_hi, dlo, a.Xp, a.ldp, a.S, a.freqs,
+                                                          a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale,
+                                                          reinterpret_cast<float*>(a.scratch), line_cap);
   FSW_LAUNCH_CHECK();
   return 0;
 }
@@ -1083,6 +1185,187 @@ static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t
   FSW_LAUNCH_CHECK();
   return 0;
 }
+
+
+#if FSW_HUB_PART == 2
+// ---- general weights, rows above kHubWMaxDeg: sorted (key, weight) blocks of 8192 + merge-path levels (merge_path.h) --------------
+// Phase A is k_embed_hub_w<4, 32>'s line for every block of 8192 elements (the pad element is element D of the line), parked in the
+// workgroup's scratch lines; one merge-path pass per level; the last pass feeds the readout, whose cumulative weight runs on from
+// tile to tile (float64, as in k_embed_hub_w).  Replaces the scratch-line kernel of embed_wsort.hip for rows without edge features:
+// 28 bitonic sweeps of a 150 000-neighbour line by ONE wavefront became 5 passes by a workgroup.
+//
+// readout of N consecutive ranks per thread, threads in rank order (wavefront w, lane, j): returns the thread's partial sum and
+// advances `carry` (the cumulative weight before the workgroup's first element) by the workgroup's total
+template <int N>
+__device__ __forceinline__ float weighted_readout(const float* __restrict__ kk, const float* __restrict__ ww, int r0, int Dtot, double xi,
+                                                  double inv, bool lin, double& carry, double* __restrict__ redd, int w, int lane) {
+  constexpr int NW = kMpNT / kWave;
+  double lsum = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) lsum += (double)ww[j];
+  double cw = wave_exclusive_scan_f64_h(lsum, lane);
+  const double wtot = __shfl(cw + lsum, kWave - 1);
+  if (lane == 0) redd[w] = wtot;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    if (q < w) cw += redd[q];
+    tot += redd[q];
+  }
+  __syncthreads();
+  cw += carry;
+  carry += tot;
+  float acc = 0.f;
+  float sprev = lin ? 0.f : sin2pi_rev_h(xi * (cw * inv));
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const bool valid = r0 + j < Dtot;
+    cw += (double)ww[j];
+    if (lin) {
+      acc += valid ? ww[j] * kk[j] : 0.f;
+    } else {
+      const float sn = sin2pi_rev_h(xi * (cw * inv));
+      acc += valid ? (sn - sprev) * kk[j] : 0.f;
+      sprev = sn;
+    }
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ wgt, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ bin_start, int bin_lo, int bin_hi, int dlo, const float* __restrict__ Xp, int64_t ldp, int S,
+    const float* __restrict__ freqs, float tau, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
+    int has_mass, int mass_fn, float mass_scale, float* __restrict__ scratch, int64_t line_cap) {
+  constexpr int NW = 4, M = 32, CAP = M * kWave;
+  static_assert(NW * CAP == kMpBlk && NW * kWave == kMpNT, "block = one workgroup's registers");
+  extern __shared__ __attribute__((aligned(16))) float xsm[];   // phase A: keys [NW][CAP] | weights [NW][CAP]; levels: tiles | boundaries
+  __shared__ double redd[NW];
+  __shared__ float red[NW];
+  float* xk = xsm;
+  float* xw = xsm + NW * CAP;
+  float* tk = xsm;
+  float* tw = xsm + kMpTileLds;
+  int* part = reinterpret_cast<int*>(xsm + 2 * kMpTileLds);
+  const int pbeg = bin_start[bin_lo], nrows = bin_start[bin_hi + 1] - pbeg;
+  const int lane = lane_id(), w = wave_id();
+  const int blk = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  float* k0 = scratch + (int64_t)blk * 4 * line_cap;
+  float* k1 = k0 + line_cap;
+  float* w0 = k1 + line_cap;
+  float* w1 = w0 + line_cap;
+  const int64_t nlines = (int64_t)nrows * S;
+  for (int64_t line = blk; line < nlines; line += gridDim.x) {
+    const int p = pbeg + (int)(line / S), k = (int)(line % S);
+    const int node = perm[p];
+    const int start = rowptr[node];
+    const int D = rowptr[node + 1] - start;
+    if (D <= dlo) continue;
+    const int Dtot = D + 1;                                 // with the reference's pad element (fsw_embedding.py:1000-1017)
+    const int nb = (Dtot + kMpBlk - 1) / kMpBlk;
+    // total mass of the row
+    double pm = 0.0;
+    for (int t = threadIdx.x; t < D; t += kMpNT) pm += (double)(wgt ? wgt[start + t] : 1.f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+    if (lane == 0) redd[w] = pm;
+    __syncthreads();
+    double m = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) m += redd[q];
+    __syncthreads();
+    const double taud = (double)tau;
+    const double inv = 1.0 / fmax(m, taud);
+    const float padw = (float)fmax(taud - m, 0.0);
+    const float xif = freqs[k];
+    const double xi = (double)xif;
+    const bool lin = xif < 1e-30f;
+    WaveLine<M, true> ln;
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+      const int t0 = b * kMpBlk + w * CAP;
+#pragma unroll
+      for (int h = 0; h < M; h += 16) {                     // two batches of 16 gathers: the index registers are the budget
+        int c[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int t = t0 + (h + j) * kWave + lane;
+          c[j] = t < D ? col[start + t] : -1;
+          ln.w[h + j] = t < D ? (wgt ? wgt[start + t] : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ln.k[h + j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
+      }
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        if (t0 + j * kWave + lane == D) {
+          ln.k[j] = 0.f;
+          ln.w[j] = padw;
+        }
+      ln.sort();
+#pragma unroll
+      for (int size = 2; size <= NW; size <<= 1) {
+        wave_exchange_w<M>(ln, xk, xw, w, lane, w ^ (size - 1), true, (w & (size >> 1)) == 0);
+        for (int st = size >> 2; st >= 1; st >>= 1) wave_exchange_w<M>(ln, xk, xw, w, lane, w ^ st, false, (w & st) == 0);
+        ln.merge_chunk();
+      }
+      if (nb == 1) break;
+      const int64_t o = (int64_t)b * kMpBlk + w * CAP + lane * M;
+#pragma unroll
+      for (int j = 0; j < M; j += 4) {
+        *reinterpret_cast<float4*>(k0 + o + j) = make_float4(ln.k[j], ln.k[j + 1], ln.k[j + 2], ln.k[j + 3]);
+        *reinterpret_cast<float4*>(w0 + o + j) = make_float4(ln.w[j], ln.w[j + 1], ln.w[j + 2], ln.w[j + 3]);
+      }
+    }
+    float acc = 0.f;
+    double carry = 0.0;
+    if (nb == 1) {
+      acc = weighted_readout<M>(ln.k, ln.w, w * CAP + lane * M, Dtot, xi, inv, lin, carry, redd, w, lane);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+      merge_path_levels<true>(k0, k1, w0, w1, nb, tk, tw, part, [&](int r0, const float* ok, const float* ow) {
+        acc += weighted_readout<kMpVT>(ok, ow, r0, Dtot, xi, inv, lin, carry, redd, w, lane);
+      });
+    }
+    acc *= lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiH * xi));
+    acc = wave_sum_h(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot += red[q];
+      float* orow = out + (int64_t)node * ldo;
+      orow[has_mass + k] = out_scale * (tot + (bias ? bias[has_mass + k] : 0.f));
+      if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    }
+    __syncthreads();
+  }
+}
+
+// general weights without edge features: rows of the bins bin_lo .. bin_hi with more than dlo neighbours
+int launch_embed_mergepath_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int dlo, int64_t rows_upper, hipStream_t stream) {
+  rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
+  if (rows_upper <= 0 || (a.max_degree > 0 && a.max_degree <= dlo)) return 0;
+  FSW_REQUIRE(a.max_degree > dlo, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
+  FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");
+  FSW_REQUIRE(((uintptr_t)a.scratch & 15) == 0, "fsw_embed_f32: scratch must be 16-byte aligned");
+  const int64_t line_cap = ceil_div(a.max_degree + 1, kMpBlk) * kMpBlk;
+  int64_t nwg = std::min<int64_t>((int64_t)(a.scratch_bytes / (size_t)(4 * line_cap * 4)), 512);   // two workgroups per CU
+  nwg = std::min<int64_t>(nwg, ceil_div(rows_upper * a.S, 8) * 8);
+  if (nwg >= 8) nwg &= ~(int64_t)7;
+  FSW_REQUIRE(nwg >= 1, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
+  const size_t lds = sizeof(float) * 2 * 4 * 32 * kWave;   // phase A's (key, weight) exchange buffers; the tiles + boundaries fit inside
+  static_assert(sizeof(float) * 2 * kMpTileLds + sizeof(int) * (kMpParts + 1) <= sizeof(float) * 2 * 4 * 32 * kWave, "LDS of the merge levels");
+  k_embed_mergepath_w<<<(unsigned)nwg, kMpNT, lds, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, dlo, a.Xp, a.ldp, a.S,
+                                                            a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
+                                                            a.mass_scale, reinterpret_cast<float*>(a.scratch), line_cap);
+  FSW_LAUNCH_CHECK();
+  return 0;
+}
+#endif   // FSW_HUB_PART == 2
 
 #define FSW_HW(NW, M, LO, HI, DLO, DHI) \
   if ((rc = launch_hub_w<NW, M>(a, LO, HI, rows_upper, stream, DLO, DHI))) return rc

@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256) k_embed_wsort_global(const int32_t* __res
 int launch_embed_ws_unit(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);   // embed_hub.hip
 int launch_embed_hub_weighted_lds(const fsw_embed_args& a, int bin_lo, int64_t rows_upper, hipStream_t stream);
 int launch_embed_hub_weighted_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t stream);
+int launch_embed_mergepath_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int dlo, int64_t rows_upper, hipStream_t stream);
 #ifndef FSW_WEIGHTED_HUB
 #define FSW_WEIGHTED_HUB 1   // 0: general weights on the LDS-staged / scratch-line kernels of this file only (for comparison)
 #endif
@@ -436,6 +437,8 @@ int launch_embed_global(const fsw_embed_args& a, int64_t rows_upper, hipStream_t
     dlo = kHubWMaxDeg;
     if (a.max_degree > 0 && a.max_degree <= kHubWMaxDeg) return 0;
     if (bin_rows_or(a, first_bin, FSW_BIN_GLOBAL, 1) <= 0) return 0;
+    // above: sorted blocks + merge-path levels (embed_hub.hip); FSW_WEIGHTED_SCRATCH=1 keeps the scratch-line kernel below, for comparison
+    if (!getenv("FSW_WEIGHTED_SCRATCH")) return launch_embed_mergepath_w(a, first_bin, FSW_BIN_GLOBAL, dlo, rows_upper, stream);
   }
   FSW_REQUIRE(a.max_degree > FSW_LDS_MAX_DEG, "fsw_embed_f32: max_degree (host value) is required for rows above FSW_LDS_MAX_DEG");
   FSW_REQUIRE(a.scratch, "fsw_embed_f32: these rows need a scratch buffer (fsw_embed_scratch_bytes)");

@@ -47,9 +47,10 @@ typedef void* fsw_stream_t; /* a hipStream_t (torch.cuda.current_stream().cuda_s
  *                                      wavefronts holds ONE slice's line in its registers, 2048 keys per wavefront; the merge
  *                                      levels above one wavefront exchange registers through LDS)
  *   bin FSW_BIN_GLOBAL               : degree > FSW_HUB_MAX_DEG (global-scratch bitonic path, any degree)
- * General (non-unit) weights carry a weight next to every key, so their per-lane register path ends at
- * FSW_MID_MAX_DEG_WEIGHTED and the bins above it run on the wave-sort path; weighted rows above FSW_LDS_MAX_DEG all take
- * the global-scratch path.                                                                                            */
+ * General (non-unit) weights carry a weight next to every key and a line holds one more element (the reference's pad element), so
+ * their per-lane register path ends at FSW_MID_MAX_DEG_WEIGHTED; above it (key, weight) lines of 64 x {3 .. 32} keys per lane on
+ * one, two or four wavefronts take rows of up to 8191 neighbours, sorted blocks of 8192 + merge-path levels the rest
+ * (csrc/embed_hub.hip, csrc/merge_path.h); with edge features the LDS-staged / scratch-line kernels of csrc/embed_wsort.hip.      */
 #define FSW_REG_MAX_DEG 32
 #define FSW_NUM_MID_BINS 9
 #define FSW_MID_SIZES {40, 48, 64, 80, 96, 128, 160, 192, 256}

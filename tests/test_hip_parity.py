@@ -377,16 +377,19 @@ def test_wave_sort_rows_every_size_class(dev, S):
 
 
 @pytest.mark.parametrize("S", [11, 12])
-def test_hub_rows_every_size_class(dev, S):
-    """Rows of 2049..33000 neighbours at both ends of the four hub classes (csrc/embed_hub.hip: a workgroup of 2 / 4 / 8 / 16
-    wavefronts holds one slice's line, 2048 keys per wavefront, merge levels above a wavefront through LDS) and one row above
-    them (k_embed_giant: blocks of 32768 keys); unit weights take the hub kernels, general weights k_embed_hub_w up to 4096
-    neighbours and the scratch-line kernel above; a zero frequency; several rows per class so that the XCD-interleaved block order
-    is exercised.  S = 11: 4-byte gathers; S = 12 (a multiple of 4): the 16-byte gather forms."""
+def test_hub_rows_every_size_class(dev, S, monkeypatch):
+    """Rows of 2049..70001 neighbours at both ends of the four hub classes (csrc/embed_hub.hip: a workgroup of 2 / 4 / 8 / 16
+    wavefronts holds one slice's line, 2048 keys per wavefront, merge levels above a wavefront through LDS) and two rows above
+    them (k_embed_giant: blocks of 16384 keys + block sweeps; with FSW_GIANT_MERGEPATH=1 k_embed_mergepath: blocks of 8192 +
+    merge-path levels, 5 and 9 blocks = runs without a partner at two levels); general weights: k_embed_hub_w's capacity classes up
+    to 8191 neighbours, above them k_embed_mergepath_w ((key, weight) blocks of 8192 + merge-path levels, csrc/merge_path.h); a zero
+    frequency; a mass-deficient row; several rows per class so that the XCD-interleaved block order is exercised.
+    S = 11: 4-byte gathers; S = 12 (a multiple of 4): the 16-byte gather forms."""
     from fsw_gnn_amd import build_csr, _lib
     rng = np.random.default_rng(29)
-    sizes = [2049, 4096, 4097, 8192, 8193, 16384, 16385, 32768, 33000, 3000, 5000, 6000, 7000, 4100, 9000, 9001, 9002, 2500]
-    nrows, n, d = len(sizes), 40_000, 6
+    sizes = [2049, 4096, 4097, 8192, 8193, 16384, 16385, 32768, 33000, 3000, 5000, 6000, 7000, 4100, 9000, 9001, 9002, 2500, 70001,
+             8191, 6143, 6144, 3071, 3072, 4095]
+    nrows, n, d = len(sizes), 80_000, 6
     X = rng.standard_normal((n, d)).astype(np.float32)
     V = cases.synth.unit_slices(S, d, seed=87)
     fr = cases.random_freqs(S, seed=88)
@@ -395,15 +398,20 @@ def test_hub_rows_every_size_class(dev, S):
     snd = np.concatenate([rng.choice(n, size=k, replace=False) for k in sizes]).astype(np.int64)
     w = (rng.random(rec.size) + 0.1).astype(np.float32)
     w[rec == 0] *= 0.3 / w[rec == 0].sum()
+    w[rec == 18] *= 0.4 / w[rec == 18].sum()          # the longest row is mass-deficient too: its pad element carries weight
     rowptr = np.concatenate([[0], np.cumsum(sizes)])
-    for weights in (None, w):
+    for weights, giant_merge_path in ((None, False), (None, True), (w, False)):
+        if giant_merge_path:
+            monkeypatch.setenv("FSW_GIANT_MERGEPATH", "1")
+        else:
+            monkeypatch.delenv("FSW_GIANT_MERGEPATH", raising=False)
         E = make_embedding(dev, V, fr, enable_bias=False, encode_total_mass=True)
         with torch.no_grad():
             graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), nrows, n)
             out = torch.empty((nrows, S + 1), device=dev)
             E.embed_into(t(X, dev), graph, out)
         bs = np.diff(graph.bin_start.cpu().numpy())
-        assert bs[-5:].tolist() == [4, 6, 5, 2, 1] and bs[:-5].sum() == 0 and graph.stats()[_lib.STAT_NUM_GLOBAL] == nrows
+        assert bs[-5:].tolist() == [7, 9, 5, 2, 2] and bs[:-5].sum() == 0 and graph.stats()[_lib.STAT_NUM_GLOBAL] == nrows
         ref = C.embed(X, rowptr, snd, weights, V, fr)
         got = out.cpu().numpy()
         assert relerr(got[:, 1:], ref) < TOL
