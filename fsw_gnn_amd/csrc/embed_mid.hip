@@ -18,6 +18,10 @@
 #include <stdlib.h>
 #include "sortnet.h"
 
+#ifndef FSW_MID_ROW_BARRIER
+#define FSW_MID_ROW_BARRIER 0
+#endif
+
 namespace fsw {
 
 constexpr double kPiM = 3.14159265358979323846;
@@ -51,6 +55,9 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
   const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
   const float* xk = Xp + kc;
   for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
+#if FSW_MID_ROW_BARRIER
+    if (DP >= FSW_MID_ROW_BARRIER) __builtin_amdgcn_s_barrier();   // the four wavefronts walk the unrolled network together (instruction cache)
+#endif
     const int node = perm[p];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;   // FSW_REG_MAX_DEG < D <= DP
@@ -61,27 +68,145 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
       if (t < D) net.k[t] = xk[(int64_t)col[start + t] * ldp];
     }
     sort_network<DP>(net);
+    // D in a vector register the compiler cannot prove uniform: `r < D` with a scalar D becomes one 64-bit lane mask per wire, all
+    // of them computed up front and spilled (v_writelane + 2-3 v_readlane per wire); a vector compare is one instruction
+    int Dv = D;
+    asm volatile("" : "+v"(Dv));
     float acc = b;
     if (lin) {
       const float coef = out_scale * 2.f / (float)D;
 #pragma unroll
       for (int r = 0; r < DP; ++r)
-        if (r < D) acc = fmaf(coef, net.k[r], acc);
+        acc = fmaf(coef, r < Dv ? net.k[r] : 0.f, acc);
     } else {
       // coefficient of rank r = B cos(2 pi xi (r + 1/2) / D): one float64 FMA per rank (UnitCoef, fsw_common.h)
       UnitCoef uc;
       uc.start(xi, D, 0);
       float a2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < DP; ++r) {
-        if (r < D) a2 = fmaf(uc.next(), net.k[r], a2);
-      }
+      for (int r = 0; r < DP; ++r) a2 = fmaf(uc.next(), r < Dv ? net.k[r] : 0.f, a2);  // the recurrence itself runs unconditionally:
+                                                                                     // under `if (r < D)` its four state registers
+                                                                                     // were re-selected at every wire
       acc = fmaf(out_scale * uc.B, a2, acc);
     }
     float* orow = out + (int64_t)node * ldo;
     orow[has_mass + kc] = acc;
     if (has_mass && chunk == 0 && lane_id() == 0)
       orow[0] = out_scale * (mass_encode_m((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+  }
+}
+
+// The same kernel with the NEXT row's gather in flight while this row is sorted (rows of 97+ neighbours): at one or two wavefronts per
+// SIMD nothing else covers the 2-3 us between issuing a row's gathers and their arrival -- a quarter to a third of a row's time.
+//   * the column indices arrive two rows ahead as ceil(DP / 64) coalesced VECTOR loads (lane l holds col[start + 64 q + l]) and are
+//     handed to the address arithmetic by v_readlane -- D scalar loads in batches of 16 with a wait per batch were a serial chain of
+//     their own;
+//   * the keys of row i + 1 (the first PF wires; PF = DP except for the 256-wire network, whose line leaves 128 registers free) are
+//     gathered into a second register set right before row i is sorted and copied into the network's wires at the top of the next
+//     iteration (PF moves against ~25 DP network instructions).
+// One wavefront per SIMD (2 DP + ~40 registers) -- the unpipelined form runs DP = 96 / 128 at two.
+template <int DP, int PF>
+__global__ void __launch_bounds__(256, 1) k_embed_mid_unit_pf(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
+                                                           int bin, const float* __restrict__ Xp, int64_t ldp, int S,
+                                                           const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo,
+                                                           const float* __restrict__ bias, float out_scale, int has_mass,
+                                                           int mass_fn, float mass_scale) {
+  static_assert(PF >= 0 && PF <= DP, "prefetched wires");
+  constexpr int NCV = (DP + kWave - 1) / kWave;
+  const int chunk = blockIdx.y * 4 + wave_id();
+  if (chunk * kWave >= S) return;
+  const int lane = lane_id();
+  const int kc = min(chunk * kWave + lane, S - 1);
+  const int pbeg = bin_start[bin], pend = bin_start[bin + 1];
+  const float xif = freqs[kc];
+  const double xi = (double)xif;
+  const bool lin = xif < 1e-30f;
+  const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
+  const float* xk = Xp + kc;
+  const int stride = gridDim.x;
+  struct Row {
+    int node, start, D;
+  };
+  auto describe = [&](int p) {
+    Row r{-1, 0, 0};
+    if (p < pend) {
+      r.node = perm[p];
+      r.start = rowptr[r.node];
+      r.D = rowptr[r.node + 1] - r.start;
+    }
+    return r;
+  };
+  auto load_cols = [&](const Row& r, int (&cv)[NCV]) {
+#pragma unroll
+    for (int q = 0; q < NCV; ++q) cv[q] = col[r.start + min(q * kWave + lane, max(r.D - 1, 0))];   // wires >= D: the last neighbour again
+  };
+  int p = pbeg + blockIdx.x;
+  Row cur = describe(p), nxt = describe(p + stride);
+  int cvc[NCV], cvn[NCV];
+  load_cols(cur, cvc);
+  load_cols(nxt, cvn);
+  // Every wire is gathered (wires >= D re-read the last neighbour's line and are overwritten by +inf): a branch per wire puts
+  // every load into its own basic block, and the wait-count pass then drains the memory pipe (vmcnt(0)) at every one of them.
+  float nk[PF > 0 ? PF : 1];
+#pragma unroll
+  for (int t = 0; t < PF; ++t) {
+    nk[t] = xk[(int64_t)__builtin_amdgcn_readlane(cvc[t / kWave], t % kWave) * ldp];
+    if ((t & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+  }
+  for (; p < pend; p += stride) {
+    KeyNet<DP> net;
+    const int D = cur.D;
+    int Dm = D;
+    asm volatile("" : "+v"(Dm));                          // vector compares for the padding masks (see the readout)
+#pragma unroll
+    for (int t = 0; t < PF; ++t) net.k[t] = t < Dm ? nk[t] : __builtin_inff();
+    // wires beyond the prefetch set (PF = 0: all of them) are gathered now.  A scheduling barrier every 16 loads: left alone the
+    // scheduler computes all DP scalar addresses first and spills them (v_writelane / v_readlane, two per load)
+#pragma unroll
+    for (int t = PF; t < DP; ++t) {
+      net.k[t] = xk[(int64_t)__builtin_amdgcn_readlane(cvc[t / kWave], t % kWave) * ldp];
+      if ((t & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+    // row i + 1: keys on their way while row i is sorted; row i + 2: its column indices
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      nk[t] = xk[(int64_t)__builtin_amdgcn_readlane(cvn[t / kWave], t % kWave) * ldp];
+      if ((t & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = PF; t < DP; ++t) net.k[t] = t < Dm ? net.k[t] : __builtin_inff();
+    const Row nn = describe(p + 2 * stride);
+#pragma unroll
+    for (int q = 0; q < NCV; ++q) cvc[q] = cvn[q];
+    load_cols(nn, cvn);
+    sort_network<DP>(net);
+    // D in a vector register the compiler cannot prove uniform: `r < D` with a scalar D becomes one 64-bit lane mask per wire, all
+    // of them computed up front and spilled (v_writelane + 2-3 v_readlane per wire); a vector compare is one instruction
+    int Dv = D;
+    asm volatile("" : "+v"(Dv));
+    float acc = b;
+    if (lin) {
+      const float coef = out_scale * 2.f / (float)D;
+#pragma unroll
+      for (int r = 0; r < DP; ++r)
+        acc = fmaf(coef, r < Dv ? net.k[r] : 0.f, acc);
+    } else {
+      UnitCoef uc;
+      uc.start(xi, D, 0);
+      float a2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < DP; ++r) a2 = fmaf(uc.next(), r < Dv ? net.k[r] : 0.f, a2);  // the recurrence itself runs unconditionally:
+                                                                                     // under `if (r < D)` its four state registers
+                                                                                     // were re-selected at every wire
+      acc = fmaf(out_scale * uc.B, a2, acc);
+    }
+    float* orow = out + (int64_t)cur.node * ldo;
+    orow[has_mass + kc] = acc;
+    if (has_mass && chunk == 0 && lane == 0)
+      orow[0] = out_scale * (mass_encode_m((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    cur = nxt;
+    nxt = nn;
   }
 }
 
@@ -175,6 +300,24 @@ int launch_embed_mid_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_
                                                  a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,       \
                                                  a.mass_scale);                                                           \
   FSW_LAUNCH_CHECK()
+#ifndef FSW_MID_PF_MIN
+#define FSW_MID_PF_MIN 192    // networks of at least this many wires prefetch the next row's keys (k_embed_mid_unit_pf<DP, PF > 0>)
+#endif
+#ifndef FSW_MID_VCOL_MIN
+#define FSW_MID_VCOL_MIN 1000 // ... of at least this many: vector column loads + branch-free gathers, no key prefetch (PF = 0)
+#endif
+#define FSW_MID_UNIT_PF(i, DP, PF)                                                                                        \
+  if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0) {                                                          \
+    if constexpr (DP >= FSW_MID_PF_MIN || DP >= FSW_MID_VCOL_MIN)                                                         \
+      k_embed_mid_unit_pf<DP, (DP >= FSW_MID_PF_MIN ? PF : 0)><<<grid, 256, 0, stream>>>(                                 \
+          a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp, a.S, a.freqs, a.out, a.ldo, a.bias,        \
+          a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);                                                              \
+    else                                                                                                                  \
+      k_embed_mid_unit<DP><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp, a.ldp,  \
+                                                     a.S, a.freqs, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,         \
+                                                     a.mass_fn, a.mass_scale);                                            \
+  }                                                                                                                       \
+  FSW_LAUNCH_CHECK()
 #define FSW_MID_WEIGHTED(i, DP)                                                                                           \
   if (bin_rows_or(a, FSW_BIN_MID0 + i, FSW_BIN_MID0 + i, 1) > 0)                                                            \
   k_embed_mid_weighted<DP + 1><<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, FSW_BIN_MID0 + i, a.Xp,  \
@@ -185,7 +328,8 @@ int launch_embed_mid_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_
 
 #if FSW_MID_PART == 0
 int launch_mid_unit_small(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
-  FSW_MID_UNIT(0, 40); FSW_MID_UNIT(1, 48); FSW_MID_UNIT(2, 64); FSW_MID_UNIT(3, 80); FSW_MID_UNIT(4, 96); FSW_MID_UNIT(5, 128);
+  FSW_MID_UNIT_PF(0, 40, 40); FSW_MID_UNIT_PF(1, 48, 48); FSW_MID_UNIT_PF(2, 64, 64); FSW_MID_UNIT_PF(3, 80, 80); FSW_MID_UNIT_PF(4, 96, 96);
+  FSW_MID_UNIT_PF(5, 128, 128);
   return 0;
 }
 
@@ -209,7 +353,7 @@ int launch_embed_mid(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
 }
 #elif FSW_MID_PART == 1
 int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
-  FSW_MID_UNIT(6, 160); FSW_MID_UNIT(7, 192); FSW_MID_UNIT(8, 256);
+  FSW_MID_UNIT_PF(6, 160, 160); FSW_MID_UNIT_PF(7, 192, 192); FSW_MID_UNIT_PF(8, 256, 128);
   return 0;
 }
 #else
@@ -220,6 +364,7 @@ int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream) 
 }
 #endif
 #undef FSW_MID_UNIT
+#undef FSW_MID_UNIT_PF
 #undef FSW_MID_WEIGHTED
 
 }  // namespace fsw
