@@ -1378,6 +1378,10 @@ int launch_embed_hub_weighted_lds(const fsw_embed_args& a, int bin_lo, int64_t r
   // wires instead of 768, the one row of exactly 512 (513 elements) on 768.  Rows outside a launch's window cost two loads.
   int rc;
   constexpr int B160 = FSW_BIN_LDS0 - 3, B192 = FSW_BIN_LDS0 - 2, B256 = FSW_BIN_LDS0 - 1;   // mid bins ..160, ..192, ..256
+  constexpr int B40 = FSW_BIN_MID0, B64 = FSW_BIN_MID0 + 2, B128 = FSW_BIN_MID0 + 5;          // ..40, ..64, ..128
+  if (bin_lo <= B64) FSW_HW(1, 1, std::max(bin_lo, B40), B64, 0, 63);
+  if (bin_lo <= B128) FSW_HW(1, 2, std::max(bin_lo, B64), B128, 63, 127);
+  if (bin_lo <= B128) FSW_HW(1, 3, B128, B128, 127, 191);
   if (bin_lo <= B160) FSW_HW(1, 3, std::max(bin_lo, B160), B160, 0, 191);
   if (bin_lo <= B256) FSW_HW(1, 4, std::max(bin_lo, B192), B256, 0, 255);
   if (bin_lo <= B256) FSW_HW(1, 6, B256, B256, 255, 383);

@@ -358,8 +358,14 @@ int launch_mid_unit_large(const fsw_embed_args& a, dim3 grid, hipStream_t stream
 }
 #else
 int launch_mid_weighted(const fsw_embed_args& a, dim3 grid, hipStream_t stream) {
-  FSW_MID_WEIGHTED(0, 40); FSW_MID_WEIGHTED(1, 48); FSW_MID_WEIGHTED(2, 64); FSW_MID_WEIGHTED(3, 80);
-  FSW_MID_WEIGHTED(4, 96); FSW_MID_WEIGHTED(5, 128);
+  // without edge features the bins from weighted_hub_first_mid_bin() on run on k_embed_hub_w (embed_wsort.hip: launch_embed_lds)
+  const int end = a.efeat ? 6 : weighted_hub_first_mid_bin();
+  if (end > 0) { FSW_MID_WEIGHTED(0, 40); }
+  if (end > 1) { FSW_MID_WEIGHTED(1, 48); }
+  if (end > 2) { FSW_MID_WEIGHTED(2, 64); }
+  if (end > 3) { FSW_MID_WEIGHTED(3, 80); }
+  if (end > 4) { FSW_MID_WEIGHTED(4, 96); }
+  if (end > 5) { FSW_MID_WEIGHTED(5, 128); }
   return 0;
 }
 #endif

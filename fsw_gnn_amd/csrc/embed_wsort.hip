@@ -485,7 +485,7 @@ int launch_embed_lds(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
     constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
     int bin_lo = FSW_BIN_MID0;
     while (bin_lo < FSW_BIN_LDS0 && sizes[bin_lo - FSW_BIN_MID0] <= FSW_MID_MAX_DEG_WEIGHTED) ++bin_lo;
-    if (FSW_WEIGHTED_HUB && !a.efeat) return launch_embed_hub_weighted_lds(a, bin_lo, rows_upper, stream);
+    if (FSW_WEIGHTED_HUB && !a.efeat) return launch_embed_hub_weighted_lds(a, FSW_BIN_MID0 + weighted_hub_first_mid_bin(), rows_upper, stream);
     if (bin_lo < FSW_BIN_LDS0 && (rc = launch_wsort<8, true>(a, bin_lo, FSW_BIN_LDS0 - 1, rows_upper, stream))) return rc;
     if ((rc = launch_wsort<16, true>(a, FSW_BIN_LDS0, FSW_BIN_LDS0, rows_upper, stream))) return rc;
     if ((rc = launch_wsort<32, true>(a, FSW_BIN_LDS0 + 1, FSW_BIN_LDS0 + 1, rows_upper, stream))) return rc;

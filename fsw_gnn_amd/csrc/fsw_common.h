@@ -1,5 +1,7 @@
 // Shared host/device helpers for libfsw_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -69,6 +71,24 @@ __host__ __device__ inline int degree_bin(int deg) {
 // general weights without edge features: rows of up to this many neighbours (+ the pad element = 8192 = four wavefronts x 32 keys per
 // lane) keep their (key, weight) line in registers (embed_hub.hip: k_embed_hub_w); above, the scratch-line kernel of embed_wsort.hip
 constexpr int kHubWMaxDeg = 8191;
+
+// general weights without edge features: index (into FSW_MID_SIZES) of the first mid bin that runs on the (key, weight) lines of
+// embed_hub.hip (k_embed_hub_w) instead of the per-lane (key, weight) network of embed_mid.hip.  FSW_W_HUB_FROM = 33 | 65 | 129 in
+// the environment overrides the default (timing experiments).
+#ifndef FSW_W_HUB_FROM_DEFAULT
+#define FSW_W_HUB_FROM_DEFAULT 129
+#endif
+inline int weighted_hub_first_mid_bin() {
+  static const int idx = [] {
+    const char* e = getenv("FSW_W_HUB_FROM");
+    const int from = e ? atoi(e) : FSW_W_HUB_FROM_DEFAULT;
+    constexpr int sizes[FSW_NUM_MID_BINS] = FSW_MID_SIZES;
+    int i = 0;
+    while (i < FSW_NUM_MID_BINS && sizes[i] < from) ++i;   // first bin whose rows can have `from` neighbours or more
+    return std::min(i, 6);                                  // bins above FSW_MID_MAX_DEG_WEIGHTED never take the per-lane network
+  }();
+  return idx;
+}
 
 // rows of the degree bins lo .. hi when the caller passed the host copy of bin_start, `upper` (a bound) otherwise
 inline int64_t bin_rows_or(const fsw_embed_args& a, int lo, int hi, int64_t upper) {
