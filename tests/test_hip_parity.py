@@ -302,6 +302,42 @@ def test_long_rows_weighted_and_global_scratch_path(dev):
         assert relerr(out.cpu().numpy(), ref) < TOL
 
 
+def test_merge_path_rows_beyond_one_partition_chunk_and_with_ties(dev, monkeypatch):
+    """csrc/merge_path.h on one neighbourhood of 2.2M vertices (an FSW_readout of a whole graph): 269 sorted blocks of 8192, nine
+    merge levels with runs without a partner on several of them, more tile boundaries per level (538) than the 512 kept in LDS at a
+    time; a second, shorter row whose features are drawn from 40 distinct vectors, so that almost every key is tied (merge path keeps
+    ties in any order -- the readout must not care).  General weights (k_embed_mergepath_w, incl. a mass-deficient row) and unit
+    weights (k_embed_mergepath behind FSW_GIANT_MERGEPATH=1; the default k_embed_giant on the same rows)."""
+    from fsw_gnn_amd import build_csr
+    rng = np.random.default_rng(41)
+    sizes = [2_200_000, 50_000]
+    n, d, S = sizes[0], 5, 4
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X[:sizes[1]] = X[rng.integers(0, 40, size=sizes[1])]          # the second row reads vertices 0 .. 49 999: 40 distinct feature vectors
+    V = cases.synth.unit_slices(S, d, seed=91)
+    fr = cases.random_freqs(S, seed=92)
+    rec = np.repeat(np.arange(2), sizes).astype(np.int64)
+    snd = np.concatenate([rng.permutation(n), np.arange(sizes[1])]).astype(np.int64)
+    w = (rng.random(rec.size) + 0.1).astype(np.float32)
+    w[rec == 1] *= 0.7 / w[rec == 1].sum()                         # mass 0.7 < tau: the pad element carries 0.3
+    rowptr = np.concatenate([[0], np.cumsum(sizes)])
+    for weights, merge_path in ((w, False), (None, True), (None, False)):
+        if merge_path:
+            monkeypatch.setenv("FSW_GIANT_MERGEPATH", "1")
+        else:
+            monkeypatch.delenv("FSW_GIANT_MERGEPATH", raising=False)
+        E = make_embedding(dev, V, fr, enable_bias=False)
+        with torch.no_grad():
+            graph = build_csr(t(rec, dev, torch.int64), t(snd, dev, torch.int64), None if weights is None else t(weights, dev), 2, n)
+            out = torch.empty((2, S), device=dev)
+            E.embed_into(t(X, dev), graph, out)
+        ref = C.embed(X, rowptr, snd, weights, V, fr)
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert relerr(got, ref) < TOL, (weights is None, merge_path, relerr(got, ref))
+        assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
+
+
 def test_mid_degree_rows_every_padded_network_size(dev):
     """Rows of in-degree 33..300: both ends of every padded register-path bin (csrc/embed_mid.hip, FSW_MID_SIZES), one
     row past the last bin on the LDS path; unit weights, general weights (incl. a mass-deficient row that receives the
