@@ -1176,7 +1176,7 @@ static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t
   rows_upper = bin_rows_or(a, bin_lo, bin_hi, rows_upper);
   if (rows_upper <= 0 || dlo >= dhi || (a.max_degree > 0 && a.max_degree <= dlo)) return 0;
   const size_t lds = NW > 1 ? sizeof(float) * 2 * NW * M * kWave : 0;
-  if (lds > 64 * 1024) FSW_SET_MAX_LDS_ONCE((&k_embed_hub_w<NW, M>), lds);
+  if (lds + 1024 > 64 * 1024) FSW_SET_MAX_LDS_ONCE((&k_embed_hub_w<NW, M>), lds);   // the kernel's static LDS comes on top of the 64 KB default
   const int64_t nvirtual = ceil_div(ceil_div(rows_upper, 8) * a.S, LPB) * 8;
   const int64_t nblocks = std::min<int64_t>(nvirtual, 1ll << 20);
   k_embed_hub_w<NW, M><<<(unsigned)nblocks, NW == 1 ? 256 : NW * kWave, lds, stream>>>(
@@ -1359,6 +1359,7 @@ int launch_embed_mergepath_w(const fsw_embed_args& a, int bin_lo, int bin_hi, in
   FSW_REQUIRE(nwg >= 1, "fsw_embed_f32: scratch buffer too small for rows above FSW_LDS_MAX_DEG (need fsw_embed_scratch_bytes(max_degree))");
   const size_t lds = sizeof(float) * 2 * 4 * 32 * kWave;   // phase A's (key, weight) exchange buffers; the tiles + boundaries fit inside
   static_assert(sizeof(float) * 2 * kMpTileLds + sizeof(int) * (kMpParts + 1) <= sizeof(float) * 2 * 4 * 32 * kWave, "LDS of the merge levels");
+  FSW_SET_MAX_LDS_ONCE((&k_embed_mergepath_w), lds);   // 64 KB of dynamic LDS + the kernel's static words
   k_embed_mergepath_w<<<(unsigned)nwg, kMpNT, lds, stream>>>(a.rowptr, a.col, a.w, a.perm, a.bin_start, bin_lo, bin_hi, dlo, a.Xp, a.ldp, a.S,
                                                             a.freqs, a.tau, a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn,
                                                             a.mass_scale, reinterpret_cast<float*>(a.scratch), line_cap);
