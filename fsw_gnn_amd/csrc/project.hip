@@ -254,6 +254,23 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef FSW_PROJECT_DIRECT_C
 #define FSW_PROJECT_DIRECT_C 0   // 1: C tile stored straight from the accumulators instead of through the LDS staging tile
 #endif
+#ifndef FSW_PROJECT_STAMPS
+#define FSW_PROJECT_STAMPS 0   // 1: s_memtime stamps at the phase boundaries of k_project_bf3's tile loop, summed per wave role
+#endif                         //    (tools/exp_project_stamps.py reads them through fsw_debug_project_stamps)
+#if FSW_PROJECT_STAMPS
+__device__ unsigned long long g_proj_stamps[1024][12][8];   // [workgroup][wave][phase]: cycles; [..][7]: iterations
+#define FSW_STAMP(i)                                         \
+  do {                                                       \
+    const unsigned long long now_ = clock64();               \
+    stamp_sum[i] += now_ - stamp_last;                       \
+    stamp_last = now_;                                       \
+  } while (0)
+#else
+#define FSW_STAMP(i) do { } while (0)
+#endif
+#ifndef FSW_PROJECT_STAGGER
+#define FSW_PROJECT_STAGGER 0  // 1: the matrix block first / in the middle / last for the three wavefronts of a SIMD (see the tile loop)
+#endif
 #ifndef FSW_PROJECT_ABL
 #define FSW_PROJECT_ABL 0   // timing experiments (tools/exp_variants.sh): 1 = no MFMA, 2 = no output stores
 #endif
@@ -282,7 +299,7 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   // per SIMD at up to 256 registers, and the column groups beyond the first re-read X (from L2 / the Infinity Cache mostly).
   constexpr int B3_LD = 16 * KS + 8;
   constexpr int NQ = KS <= 8 ? 3 : 4;     // float4 of an X tile per thread (32 rows x 4 KS float4 over >= 384 (d <= 128) / 512 threads)
-  // LDS: A planes [2][3][32][B3_LD] bf16 | C staging [2][32][ldc] float | row map [2][32] int
+  // LDS: A planes [2][3][32][B3_LD] bf16 | C staging [2][32][ldc] float | row map [3][32] int
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 (*APlanes)[3][BS_ROWS][B3_LD];
   APlanes As = reinterpret_cast<APlanes>(smem);
@@ -326,6 +343,12 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
 
   const int d4 = d >> 2;
   const int per_tile = BS_ROWS * d4;
+  // i / d4, i / w1, i / w2 for the element indices i < 32 * 96 of a tile: multiply-shift instead of a division by a run-time value
+  // (~35 instructions each, eleven of them per thread and tile: the s_memtime stamps of tools/exp_project_stamps.py put the address
+  // arithmetic of the load / split / write-out phases at 46 % of a tile).  Exact for i * divisor < 2^20.
+  auto magic = [](int dv) { return dv > 0 ? (unsigned)(((1u << 20) + dv - 1) / dv) : 0u; };
+  auto fdiv = [](int i, unsigned m) { return (int)(((unsigned)i * m) >> 20); };
+  const unsigned m_d4 = magic(d4);
   int nonfinite = 0;
   struct TileRegs {
     float4 q[NQ];
@@ -337,20 +360,23 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
       t.q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int i = threadIdx.x + u * blockDim.x;
       if (i < per_tile) {
-        const int r = i / d4, c4 = i - r * d4;
+        const int r = fdiv(i, m_d4), c4 = i - r * d4;
         if (row0 + r < n) t.q[u] = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + 4 * c4);
       }
     }
   };
-  auto store_tile = [&](int buf, int64_t tile, const TileRegs& t) {
+  // rslot: slot of the tile's row map (three slots: the write-out of tile t may still read its slot while the A planes of tile
+  // t + 2 -- same A buffer, same parity -- are being written; with two slots a fast wavefront 0 could overwrite the map under a
+  // slow wavefront's write-out)
+  auto store_tile = [&](int buf, int rslot, int64_t tile, const TileRegs& t) {
     const int64_t row0 = tile * BS_ROWS;
     if (threadIdx.x < BS_ROWS)
-      rmap[buf * BS_ROWS + threadIdx.x] = (row_map && row0 + threadIdx.x < n) ? row_map[row0 + threadIdx.x] : (int)(row0 + threadIdx.x);
+      rmap[rslot * BS_ROWS + threadIdx.x] = (row_map && row0 + threadIdx.x < n) ? row_map[row0 + threadIdx.x] : (int)(row0 + threadIdx.x);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
       const int i = threadIdx.x + u * blockDim.x;
       if (i < per_tile) {
-        const int r = i / d4, c4 = i - r * d4;
+        const int r = fdiv(i, m_d4), c4 = i - r * d4;
         const float v[4] = {t.q[u].x, t.q[u].y, t.q[u].z, t.q[u].w};
         bf16x4 p1, p2, p3;
 #pragma unroll
@@ -375,16 +401,17 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   const int w2 = (nslab_waves - max(g1, 0)) * 8;                           // float4 per staged row, second block
   const int col1 = blockIdx.y * nslab_waves * 32;                          // first Xp column of this group
   const int col2 = max((int)blockIdx.y * nslab_waves - nsl1, 0) * 32;      // first Y2 column of this group
+  const unsigned m_w1 = magic(w1), m_w2 = magic(w2);
   auto write_out = [&](int cb, int64_t tile, int rb) {
     const int64_t row0 = tile * BS_ROWS;
     const float* cs = Cs + cb * BS_ROWS * ldc;
     for (int i = threadIdx.x; i < BS_ROWS * w1; i += blockDim.x) {
-      const int r = i / w1, c4 = i - r * w1;
+      const int r = fdiv(i, m_w1), c4 = i - r * w1;
       if (row0 + r < n && col1 + 4 * c4 < ldp)   // Xp rows are padded to ldp >= 32 ceil(S/32): whole float4 always fit
         *reinterpret_cast<float4*>(Xp + (row0 + r) * ldp + col1 + 4 * c4) = *reinterpret_cast<const float4*>(cs + r * ldc + 4 * c4);
     }
     for (int i = threadIdx.x; i < BS_ROWS * w2; i += blockDim.x) {
-      const int r = i / w2, c4 = i - r * w2;
+      const int r = fdiv(i, m_w2), c4 = i - r * w2;
       if (row0 + r >= n) continue;
       const int cc = col2 + 4 * c4;
       const float4 v = *reinterpret_cast<const float4*>(cs + r * ldc + max(g1, 0) * 32 + 4 * c4);
@@ -407,15 +434,25 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
   TileRegs tr;
   if (tile < ntiles) {
     load_tile(tile, tr);
-    store_tile(0, tile, tr);
+    store_tile(0, 0, tile, tr);
   }
   if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, tr);
   __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int64_t next = tile + gridDim.x, next2 = next + gridDim.x;
-    if (next < ntiles) store_tile(buf ^ 1, next, tr);
+  int buf = 0, rs = 0;                                   // A / C buffer and row-map slot of the current tile
+#if FSW_PROJECT_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last = clock64();
+#endif
+#if FSW_PROJECT_STAGGER && !FSW_PROJECT_DIRECT_C
+  // the three blocks of an iteration
+  auto move_in = [&](int64_t t) {                        // tile t + 1 from registers into the A planes, loads of tile t + 2 issued
+    const int64_t next = t + gridDim.x, next2 = next + gridDim.x;
+    if (next < ntiles) store_tile(buf ^ 1, rs == 2 ? 0 : rs + 1, next, tr);
+    FSW_STAMP(0);                                        // waited for the tile's loads, split, wrote the A planes
     if (next2 < ntiles) load_tile(next2, tr);
+    FSW_STAMP(1);                                        // loads of tile t + 2 issued
+  };
+  auto matrix = [&](int64_t t) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -432,15 +469,16 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
       }
+      FSW_STAMP(2);                                      // matrix instructions issued
 #if FSW_PROJECT_DIRECT_C
       // straight from the accumulators: every store instruction covers two rows x 32 columns = two whole 128-byte lines
       if (col_ok && !(FSW_PROJECT_ABL & 2)) {
-        const int64_t row0 = tile * BS_ROWS;
+        const int64_t row0 = t * BS_ROWS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int R = (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
           if (row0 + R < n) {
-            if (second) Y2[(int64_t)rmap[buf * BS_ROWS + R] * ldy2 + c] = acc[r] + add;
+            if (second) Y2[(int64_t)rmap[rs * BS_ROWS + R] * ldy2 + c] = acc[r] + add;
             else Xp[(row0 + R) * ldp + c] = acc[r] + add;
           }
         }
@@ -450,21 +488,121 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
       float* cs = Cs + (cbufs == 2 ? buf : 0) * BS_ROWS * ldc + wv * 32 + fr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
+      FSW_STAMP(3);                                      // accumulators drained into the staging tile
+#endif
+    } else if (cbufs == 1) {
+      __syncthreads();                   // helper waves (no slab) join the same barrier
+    }
+  };
+  // The matrix block at a different place of the iteration for each of the three wavefronts that share a SIMD (wavefront w runs on
+  // SIMD w % 4): one group's matrix instructions run under the other groups' loads / splits / stores instead of all twelve
+  // wavefronts moving data together and then queueing for the matrix pipe together.  The write-out of tile t moves into iteration
+  // t + 1 (its staging buffer and row-map slot are not reused before the barrier that ends it).
+  const int grp = cbufs == 2 ? (wv >> 2) % 3 : 2;
+  bool have_prev = false;
+  int64_t prev_tile = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    auto out_prev = [&]() {
+      if (have_prev && !(FSW_PROJECT_ABL & 2)) write_out(cbufs == 2 ? buf ^ 1 : 0, prev_tile, rs == 0 ? 2 : rs - 1);
+      FSW_STAMP(5);
+    };
+    FSW_STAMP(6);
+    if (grp == 0) {
+      matrix(tile);
+      move_in(tile);
+      out_prev();
+    } else if (grp == 1) {
+      move_in(tile);
+      matrix(tile);
+      out_prev();
+    } else {
+      move_in(tile);
+      out_prev();
+      matrix(tile);
+    }
+    __syncthreads();
+    FSW_STAMP(4);                                        // barrier
+#if FSW_PROJECT_STAMPS
+    stamp_sum[7] += 1;
+#endif
+    have_prev = true;
+    prev_tile = tile;
+    buf ^= 1;
+    rs = rs == 2 ? 0 : rs + 1;
+  }
+  if (have_prev && !(FSW_PROJECT_ABL & 2)) write_out(cbufs == 2 ? buf ^ 1 : 0, prev_tile, rs == 0 ? 2 : rs - 1);
+#else
+  // (written out inline, not through the lambdas above: the same statements through move_in() / matrix() compiled to a loop that
+  // measured 0.70-0.72 ms against 0.65-0.68 ms for this one)
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int64_t next = tile + gridDim.x, next2 = next + gridDim.x;
+    FSW_STAMP(6);                                        // tail of the previous iteration: output stores issued
+    if (next < ntiles) store_tile(buf ^ 1, rs == 2 ? 0 : rs + 1, next, tr);
+    FSW_STAMP(0);                                        // waited for the tile's loads, split, wrote the A planes
+    if (next2 < ntiles) load_tile(next2, tr);
+    FSW_STAMP(1);                                        // loads of tile t + 2 issued
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (slab_active && !(FSW_PROJECT_ABL & 1)) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][0][fr][16 * s + 8 * fh]);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[buf][1][fr][16 * s + 8 * fh]);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[buf][2][fr][16 * s + 8 * fh]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bw[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[2][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
+      }
+      FSW_STAMP(2);                                      // matrix instructions issued
+#if FSW_PROJECT_DIRECT_C
+      // straight from the accumulators: every store instruction covers two rows x 32 columns = two whole 128-byte lines
+      if (col_ok && !(FSW_PROJECT_ABL & 2)) {
+        const int64_t row0 = tile * BS_ROWS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int R = (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
+          if (row0 + R < n) {
+            if (second) Y2[(int64_t)rmap[rs * BS_ROWS + R] * ldy2 + c] = acc[r] + add;
+            else Xp[(row0 + R) * ldp + c] = acc[r] + add;
+          }
+        }
+      }
+#else
+      if (cbufs == 1) __syncthreads();   // uniform: the previous tile has left the single staging buffer
+      float* cs = Cs + (cbufs == 2 ? buf : 0) * BS_ROWS * ldc + wv * 32 + fr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * fh) * ldc] = acc[r] + add;   // C/D map of the 32x32 MFMA
+      FSW_STAMP(3);                                      // accumulators drained into the staging tile
 #endif
     } else if (cbufs == 1) {
       __syncthreads();                   // helper waves (no slab) join the same barrier
     }
     __syncthreads();
+    FSW_STAMP(4);                                        // barrier
 #if !FSW_PROJECT_DIRECT_C
-    if (!(FSW_PROJECT_ABL & 2)) write_out(cbufs == 2 ? buf : 0, tile, buf);
+    if (!(FSW_PROJECT_ABL & 2)) write_out(cbufs == 2 ? buf : 0, tile, rs);
+#endif
+    FSW_STAMP(5);                                        // staging tile read, output stores issued
+#if FSW_PROJECT_STAMPS
+    stamp_sum[7] += 1;
 #endif
     buf ^= 1;
+    rs = rs == 2 ? 0 : rs + 1;
   }
+#endif
   if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
+#if FSW_PROJECT_STAMPS
+  if (lane == 0 && blockIdx.x < 1024 && blockIdx.y == 0 && wv < 12)
+    for (int i = 0; i < 8; ++i) g_proj_stamps[blockIdx.x][wv][i] += stamp_sum[i];
+#endif
 }
 
 static size_t bf3_lds_bytes(int nwaves, int ks, int cbufs) {
-  return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * cbufs * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 2 * BS_ROWS;
+  return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * cbufs * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 3 * BS_ROWS;
 }
 
 }  // namespace fsw
@@ -555,3 +693,16 @@ extern "C" int fsw_project_linear_f32(const float* X, int64_t n, int d, int64_t 
   return project_launch(X, n, d, ldx, V, S, ldv, Xp, ldp, nullptr, 0, W2, H2, ldw2, b2, Y2, ldy2, row_map, stats,
                         reinterpret_cast<hipStream_t>(stream));
 }
+
+#if FSW_PROJECT_STAMPS
+// timing experiment only (not in include/fsw_hip.h): copies and clears the per-wave stamp sums of k_project_bf3
+// (out: [1024][12][8] unsigned 64-bit words)
+extern "C" int fsw_debug_project_stamps(unsigned long long* out) {
+  FSW_CHECK_HIP(hipDeviceSynchronize());
+  FSW_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fsw::g_proj_stamps), sizeof(unsigned long long) * 1024 * 12 * 8));
+  void* p = nullptr;
+  FSW_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(fsw::g_proj_stamps)));
+  FSW_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 12 * 8));
+  return 0;
+}
+#endif

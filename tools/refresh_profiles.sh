@@ -11,7 +11,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 "$root/bench.py" > "$out/bench.json" 2> "$out/bench.err" || { echo "bench failed"; tail -5 "$out/bench.err"; exit 1; }
 tail -c 600 "$out/bench.json"; echo
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$out/stats.log" 2>&1 || { echo "stats run failed"; tail -5 "$out/stats.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-weak > "$out/stats.log" 2>&1 || { echo "stats run failed"; tail -5 "$out/stats.log"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 "$root/bench.py" --steps 2 --warmup 1 --kernel-reps 3 --no-cpu-baseline --no-segcumsum --no-weak > "$out/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$out/pmc_fetch.log"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 "$root/bench.py" --steps 2 --warmup 1 --kernel-reps 3 --no-cpu-baseline --no-segcumsum --no-weak > "$out/pmc_write.log" 2>&1 || { echo "write pass failed"; tail -5 "$out/pmc_write.log"; exit 1; }
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/rmat22" -- python3 "$root/tools/exp_train_step.py" --rmat 22 --edges 64000000 --feat 256 --forward-only > "$out/rmat22.log" 2>&1 || { echo "rmat22 run failed"; tail -5 "$out/rmat22.log"; exit 1; }
