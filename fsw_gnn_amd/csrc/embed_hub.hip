@@ -57,14 +57,19 @@ __device__ __forceinline__ void wave_exchange(WaveLine<M, false>& ln, float* __r
                                               bool mirrored, bool lower) {
   constexpr int CAP = M * kWave;
   // one base register per side and immediate offsets j * 256 B: the asm statements keep the compiler from folding the lane
-  // term into 32 separate per-element addresses (v_bitop3 of lane ^ constant), which it then hoists out of loops and spills
-  float* mine = xbuf + w * CAP + lane;
-  asm volatile("" : "+v"(mine));
+  // term into 32 separate per-element addresses (v_bitop3 of lane ^ constant), which it then hoists out of loops and spills.
+  // The OFFSET is laundered, not the pointer: an opaque pointer loses its LDS address space and every access became a
+  // flat_load / flat_store (72 of each in k_embed_hub<4, 24>: the flat path counts on vmcnt AND lgkmcnt, so each exchange also
+  // waited for the wavefront's outstanding gathers)
+  int moff = w * CAP + lane;
+  asm volatile("" : "+v"(moff));
+  float* mine = xbuf + moff;
 #pragma unroll
   for (int j = 0; j < M; ++j) mine[j * kWave] = ln.k[j];
   __syncthreads();
-  const float* theirs = xbuf + partner * CAP + (mirrored ? kWave - 1 - lane : lane);
-  asm volatile("" : "+v"(theirs));
+  int toff = partner * CAP + (mirrored ? kWave - 1 - lane : lane);
+  asm volatile("" : "+v"(toff));
+  const float* theirs = xbuf + toff;
   const float lim = lower ? -__builtin_inff() : __builtin_inff();   // wave-uniform: min below the partner, max above it
 #pragma unroll
   for (int j = 0; j < M; ++j) ln.k[j] = minmax_by_limit(ln.k[j], theirs[(mirrored ? M - 1 - j : j) * kWave], lim);
@@ -1016,21 +1021,20 @@ template <int M>
 __device__ __forceinline__ void wave_exchange_w(WaveLine<M, true>& ln, float* __restrict__ xk, float* __restrict__ xw, int w, int lane,
                                                 int partner, bool mirrored, bool lower) {
   constexpr int CAP = M * kWave;
-  float* mk = xk + w * CAP + lane;
-  float* mw = xw + w * CAP + lane;
-  asm volatile("" : "+v"(mk));
-  asm volatile("" : "+v"(mw));
+  int moff = w * CAP + lane;                               // the offset is laundered, not the pointers (see wave_exchange)
+  asm volatile("" : "+v"(moff));
+  float* mk = xk + moff;
+  float* mw = xw + moff;
 #pragma unroll
   for (int j = 0; j < M; ++j) {
     mk[j * kWave] = ln.k[j];
     mw[j * kWave] = ln.w[j];
   }
   __syncthreads();
-  const int off = partner * CAP + (mirrored ? kWave - 1 - lane : lane);
+  int off = partner * CAP + (mirrored ? kWave - 1 - lane : lane);
+  asm volatile("" : "+v"(off));
   const float* tk = xk + off;
   const float* tw = xw + off;
-  asm volatile("" : "+v"(tk));
-  asm volatile("" : "+v"(tw));
 #pragma unroll
   for (int j = 0; j < M; ++j) {
     const int jj = (mirrored ? M - 1 - j : j) * kWave;
