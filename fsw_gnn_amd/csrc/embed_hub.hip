@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(NW* kWave, FSW_HUB_MINWAVES) k_embed_hub_q4(
       // three running pointers into the stash (lines k0 + 1 .. k0 + 3), bumped once per batch, immediate offsets inside a batch.
       // The empty asm statements make them opaque: left alone the compiler forms a 64-bit vector address for every one of the
       // 3 M stash places, hoists them out of the loop over the lines and spills them (250 registers).
-      float* p0 = swave + lane;
-      float* p1 = p0 + NW * CAP;
-      float* p2 = p1 + NW * CAP;
-      asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+      // (running OFFSETS into the wave's stash, not pointers: an opaque pointer is a generic one, and its stores became flat_store --
+      // counted on lgkmcnt as well, so every LDS exchange of the sort waited for them)
+      int o0 = lane, o1 = lane + NW * CAP, o2 = lane + 2 * NW * CAP;
+      asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
 #pragma unroll
       for (int g = 0; g < M / G; ++g) {
         if (g + 1 < M / G) {
@@ -301,24 +301,24 @@ __global__ void __launch_bounds__(NW* kWave, FSW_HUB_MINWAVES) k_embed_hub_q4(
         for (int q = 0; q < G; ++q) {
           if (w * CAP + (g * G + q) * kWave + lane >= D) v[q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
           ln.k[g * G + q] = v[q].x;
-          p0[q * kWave] = v[q].y;
-          p1[q * kWave] = v[q].z;
-          p2[q * kWave] = v[q].w;
+          swave[o0 + q * kWave] = v[q].y;
+          swave[o1 + q * kWave] = v[q].z;
+          swave[o2 + q * kWave] = v[q].w;
         }
-        p0 += G * kWave;
-        p1 += G * kWave;
-        p2 += G * kWave;
-        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));   // also keeps the batches apart (all M gathers at once: 4 M registers)
+        o0 += G * kWave;
+        o1 += G * kWave;
+        o2 += G * kWave;
+        asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));   // also keeps the batches apart (all M gathers at once: 4 M registers)
       }
     } else {
-      const float* src = swave + (sl - 1) * NW * CAP + lane;
-      asm volatile("" : "+v"(src));
+      int so = (sl - 1) * NW * CAP + lane;
+      asm volatile("" : "+v"(so));
 #pragma unroll
       for (int j = 0; j < M; ++j) {
-        ln.k[j] = src[(j % G8) * kWave];
+        ln.k[j] = swave[so + (j % G8) * kWave];
         if ((j % G8) == G8 - 1) {
-          src += G8 * kWave;
-          asm volatile("" : "+v"(src));
+          so += G8 * kWave;
+          asm volatile("" : "+v"(so));
         }
       }
     }
