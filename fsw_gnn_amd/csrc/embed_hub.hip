@@ -678,7 +678,10 @@ static int launch_hub(const fsw_embed_args& a, int bin, int64_t rows_upper, hipS
       return 0;
     }
   }
-  if constexpr (NW == 2) {
+#ifndef FSW_HUB_Q4_MAXNW
+#define FSW_HUB_Q4_MAXNW 2   // widest line (wavefronts) that takes the 16-byte gather + stash form
+#endif
+  if constexpr (NW >= 2 && NW <= FSW_HUB_Q4_MAXNW) {
     // 2049..4096 neighbours only: measured on the RMAT graphs 0.41 -> 0.36 ms (scale 20) for two wavefronts per line, but 10.2 -> 12.8 ms
     // (scale 22, 4097..8192) and no change (8193..16384) for four and eight -- there the barrier-separated exchanges between the
     // wavefronts bound the kernel, not the gather, and the stash traffic is pure cost.
