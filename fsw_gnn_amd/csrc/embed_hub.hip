@@ -1271,20 +1271,11 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
     if (D <= dlo) continue;
     const int Dtot = D + 1;                                 // with the reference's pad element (fsw_embedding.py:1000-1017)
     const int nb = (Dtot + kMpBlk - 1) / kMpBlk;
-    // total mass of the row
-    double pm = 0.0;
-    for (int t = threadIdx.x; t < D; t += kMpNT) pm += (double)(wgt ? wgt[start + t] : 1.f);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
-    if (lane == 0) redd[w] = pm;
-    __syncthreads();
-    double m = 0.0;
-#pragma unroll
-    for (int q = 0; q < NW; ++q) m += redd[q];
-    __syncthreads();
+    // total mass of the row: summed from the weights as the blocks load them (the pad element, whose weight needs it, is element
+    // D of the line = in the LAST block: one workgroup reduction there instead of a pass of its own over the row's weights)
+    double pm = 0.0, m = 0.0, inv = 0.0;
+    float padw = 0.f;
     const double taud = (double)tau;
-    const double inv = 1.0 / fmax(m, taud);
-    const float padw = (float)fmax(taud - m, 0.0);
     const float xif = freqs[k];
     const double xi = (double)xif;
     const bool lin = xif < 1e-30f;
@@ -1300,16 +1291,28 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
           const int t = t0 + (h + j) * kWave + lane;
           c[j] = t < D ? col[start + t] : -1;
           ln.w[h + j] = t < D ? (wgt ? wgt[start + t] : 1.f) : 0.f;
+          pm += (double)ln.w[h + j];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) ln.k[h + j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
       }
+      if (b == nb - 1) {                                   // every weight of the row has been read: its mass, then the pad element
 #pragma unroll
-      for (int j = 0; j < M; ++j)
-        if (t0 + j * kWave + lane == D) {
-          ln.k[j] = 0.f;
-          ln.w[j] = padw;
-        }
+        for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
+        if (lane == 0) redd[w] = pm;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NW; ++q) m += redd[q];
+        __syncthreads();
+        inv = 1.0 / fmax(m, taud);
+        padw = (float)fmax(taud - m, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+          if (t0 + j * kWave + lane == D) {
+            ln.k[j] = 0.f;
+            ln.w[j] = padw;
+          }
+      }
       ln.sort();
 #pragma unroll
       for (int size = 2; size <= NW; size <<= 1) {

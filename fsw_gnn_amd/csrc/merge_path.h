@@ -63,10 +63,11 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
   const int tid = threadIdx.x;
   const int total = nb * kMpBlk;
   float *sk = k0, *dk = k1, *sw = w0, *dw = w1;
-  for (int R = kMpBlk;; R <<= 1) {
+  for (int R = kMpBlk;; R <<= 1) {   // R <= total / 2 < 2^30 at the top of every iteration (the last level leaves by `break`)
     const int nruns = (total + R - 1) / R;              // >= 2
     const bool last = nruns == 2;
-    const int covered = min(total, (nruns >> 1) * 2 * R);   // elements that belong to a pair of runs
+    const int covered = (int)min((int64_t)total, (int64_t)(nruns >> 1) * 2 * R);   // elements that belong to a pair of runs
+    const unsigned pair_mask = 2u * (unsigned)R - 1u;   // a pair of runs is 2 R elements, R a power of two: start of a position's pair
     const int ntiles = covered / kMpTile;
     for (int g0 = 0; g0 < ntiles; g0 += kMpParts) {
       const int cnt = min(kMpParts, ntiles - g0);
@@ -75,7 +76,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
         const int pos = (g0 + i) * kMpTile;
         int v = 0;
         if (pos < covered) {
-          const int pb = pos / (2 * R) * (2 * R), d = pos - pb;
+          const int pb = (int)((unsigned)pos & ~pair_mask), d = pos - pb;
           if (d) v = merge_path_split(sk + pb, R, sk + pb + R, min(R, total - pb - R), d);
         }
         part[i] = v;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
       auto geometry = [&](int i) {
         TileGeo t;
         t.pos = (g0 + i) * kMpTile;
-        t.pb = t.pos / (2 * R) * (2 * R);
+        t.pb = (int)((unsigned)t.pos & ~pair_mask);
         const int d0 = t.pos - t.pb;
         const int nB = min(R, total - t.pb - R);
         t.a0 = part[i];
