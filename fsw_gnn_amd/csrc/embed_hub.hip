@@ -617,12 +617,13 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath(const int32_t* __r
     } else {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();
+      MpStamps st{};
       merge_path_levels<false>(k0, k1, nullptr, nullptr, nb, tk, nullptr, part, [&](int r0, const float* ok, const float*) {
         MpKeys t;
 #pragma unroll
         for (int j = 0; j < kMpVT; ++j) t.k[j] = ok[j];
         acc += unit_readout<kMpVT>(t, r0, D, xif);
-      });
+      }, st);
     }
     acc = wave_sum_h(acc);
     if (lane == 0) red[w] = acc;
@@ -1195,6 +1196,9 @@ static int launch_hub_w(const fsw_embed_args& a, int bin_lo, int bin_hi, int64_t
 
 
 #if FSW_HUB_PART == 2
+#if FSW_MP_STAMPS
+__device__ unsigned long long g_mp_stamps[512][4][16];   // [workgroup][wavefront][phase]: s_memtime ticks; [..][15]: lines
+#endif
 // ---- general weights, rows above kHubWMaxDeg: sorted (key, weight) blocks of 8192 + merge-path levels (merge_path.h) --------------
 // Phase A is k_embed_hub_w<4, 32>'s line for every block of 8192 elements (the pad element is element D of the line), parked in the
 // workgroup's scratch lines; one merge-path pass per level; the last pass feeds the readout, whose cumulative weight runs on from
@@ -1263,12 +1267,15 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
   float* w0 = k1 + line_cap;
   float* w1 = w0 + line_cap;
   const int64_t nlines = (int64_t)nrows * S;
+  MpStamps st{};
+  st.start();
   for (int64_t line = blk; line < nlines; line += gridDim.x) {
     const int p = pbeg + (int)(line / S), k = (int)(line % S);
     const int node = perm[p];
     const int start = rowptr[node];
     const int D = rowptr[node + 1] - start;
     if (D <= dlo) continue;
+    FSW_MP_MARK(st, 0);                                      // row header
     const int Dtot = D + 1;                                 // with the reference's pad element (fsw_embedding.py:1000-1017)
     const int nb = (Dtot + kMpBlk - 1) / kMpBlk;
     // total mass of the row: summed from the weights as the blocks load them (the pad element, whose weight needs it, is element
@@ -1296,6 +1303,7 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
 #pragma unroll
         for (int j = 0; j < 16; ++j) ln.k[h + j] = c[j] >= 0 ? Xp[(int64_t)c[j] * ldp + k] : __builtin_inff();
       }
+      FSW_MP_MARK(st, 1);                                  // block gathered
       if (b == nb - 1) {                                   // every weight of the row has been read: its mass, then the pad element
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pm += __shfl_xor(pm, off);
@@ -1320,6 +1328,7 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
         for (int st = size >> 2; st >= 1; st >>= 1) wave_exchange_w<M>(ln, xk, xw, w, lane, w ^ st, false, (w & st) == 0);
         ln.merge_chunk();
       }
+      FSW_MP_MARK(st, 2);                                  // block sorted (registers + two exchange levels)
       if (nb == 1) break;
       const int64_t o = (int64_t)b * kMpBlk + w * CAP + lane * M;
 #pragma unroll
@@ -1330,14 +1339,16 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
     }
     float acc = 0.f;
     double carry = 0.0;
+    FSW_MP_MARK(st, 3);                                    // blocks parked in the scratch line
     if (nb == 1) {
       acc = weighted_readout<M>(ln.k, ln.w, w * CAP + lane * M, Dtot, xi, inv, lin, carry, redd, w, lane);
     } else {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();
+      FSW_MP_MARK(st, 4);                                  // fence + barrier
       merge_path_levels<true>(k0, k1, w0, w1, nb, tk, tw, part, [&](int r0, const float* ok, const float* ow) {
         acc += weighted_readout<kMpVT>(ok, ow, r0, Dtot, xi, inv, lin, carry, redd, w, lane);
-      });
+      }, st);
     }
     acc *= lin ? 2.f * (float)inv : (float)((1.0 + xi) / (kPiH * xi));
     acc = wave_sum_h(acc);
@@ -1352,7 +1363,15 @@ __global__ void __launch_bounds__(kMpNT, 2) k_embed_mergepath_w(
       if (has_mass && k == 0) orow[0] = out_scale * (mass_encode_h((float)m, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
     }
     __syncthreads();
+    FSW_MP_MARK(st, 10);                                   // workgroup sum + store
+#if FSW_MP_STAMPS
+    st.sum[15] += 1;
+#endif
   }
+#if FSW_MP_STAMPS
+  if (lane == 0 && blockIdx.x < 512 && w < 4)
+    for (int i = 0; i < 16; ++i) g_mp_stamps[blockIdx.x][w][i] += st.sum[i];
+#endif
 }
 
 // general weights without edge features: rows of the bins bin_lo .. bin_hi with more than dlo neighbours
@@ -1376,6 +1395,19 @@ int launch_embed_mergepath_w(const fsw_embed_args& a, int bin_lo, int bin_hi, in
   FSW_LAUNCH_CHECK();
   return 0;
 }
+#if FSW_MP_STAMPS
+}  // namespace fsw
+// timing experiment only (not in include/fsw_hip.h): copies and clears the stamp sums of k_embed_mergepath_w ([512][4][16] words)
+extern "C" int fsw_debug_mergepath_stamps(unsigned long long* out) {
+  FSW_CHECK_HIP(hipDeviceSynchronize());
+  FSW_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fsw::g_mp_stamps), sizeof(unsigned long long) * 512 * 4 * 16));
+  void* p = nullptr;
+  FSW_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(fsw::g_mp_stamps)));
+  FSW_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 512 * 4 * 16));
+  return 0;
+}
+namespace fsw {
+#endif
 #endif   // FSW_HUB_PART == 2
 
 #define FSW_HW(NW, M, LO, HI, DLO, DHI) \

@@ -18,7 +18,30 @@
 #pragma once
 #include "fsw_common.h"
 
+#ifndef FSW_MP_STAMPS
+#define FSW_MP_STAMPS 0   // 1: s_memtime stamps of the merge-path kernels' phases (tools/exp_mergepath_stamps.py)
+#endif
+
 namespace fsw {
+
+#if FSW_MP_STAMPS
+struct MpStamps {
+  unsigned long long sum[16];
+  unsigned long long last;
+  __device__ __forceinline__ void start() { last = clock64(); }
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long now = clock64();
+    sum[i] += now - last;
+    last = now;
+  }
+};
+#define FSW_MP_MARK(st, i) (st).mark(i)
+#else
+struct MpStamps {
+  __device__ __forceinline__ void start() {}
+};
+#define FSW_MP_MARK(st, i) do { } while (0)
+#endif
 
 constexpr int kMpNT = 256;                  // threads per workgroup
 constexpr int kMpVT = 16;                   // outputs per thread and tile
@@ -59,7 +82,7 @@ __device__ __forceinline__ int merge_path_split_tile(const float* tk, int na, in
 // second line of the ping-pong.  tk / tw: kMpTileLds floats of LDS each, part: kMpParts + 1 ints.  nb >= 2.
 template <bool WEIGHTED, class Consume>
 __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w0, float* w1, int nb, float* tk, float* tw, int* part,
-                                                  Consume&& consume) {
+                                                  Consume&& consume, MpStamps& st) {
   const int tid = threadIdx.x;
   const int total = nb * kMpBlk;
   float *sk = k0, *dk = k1, *sw = w0, *dw = w1;
@@ -82,6 +105,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
         part[i] = v;
       }
       __syncthreads();
+      FSW_MP_MARK(st, 5);                                 // tile boundaries of the level (binary searches in the scratch line)
       // geometry of tile i of this chunk: start of its pair, offset in the pair, A- and B-parts
       struct TileGeo {
         int pos, pb, a0, b0, na;
@@ -120,6 +144,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
           if constexpr (WEIGHTED) tw[mp_pad(tid + u * kMpNT)] = pw[u];
         }
         __syncthreads();
+        FSW_MP_MARK(st, 6);                               // tile staged in LDS (waited for its loads)
         if (i + 1 < cnt) fetch(geometry(i + 1));
         const int dd = tid * kMpVT;
         int ia = merge_path_split_tile(tk, na, nbb, dd);
@@ -148,6 +173,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
             wb = ta ? wb : wn;
           }
         }
+        FSW_MP_MARK(st, 7);                               // split at the thread's diagonal + serial merge
         if (last) {
           consume(pos + dd, ok, ow);                             // one pair is left: pb == 0, pos is the rank of the tile's first output
         } else {
@@ -161,6 +187,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
           }
         }
         __syncthreads();                                          // the tile buffers are overwritten next
+        FSW_MP_MARK(st, 8);                               // readout / stores of the outputs + barrier
       }
     }
     if (last) break;
@@ -176,6 +203,7 @@ __device__ __forceinline__ void merge_path_levels(float* k0, float* k1, float* w
     __syncthreads();
     float* t = sk; sk = dk; dk = t;
     t = sw; sw = dw; dw = t;
+    FSW_MP_MARK(st, 9);                                   // copy of a run without a partner, fence, barrier
   }
 }
 
