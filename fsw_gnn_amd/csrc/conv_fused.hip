@@ -31,7 +31,24 @@
 #define FSW_FUSED_PIPE_BARRIER 0   // measured: tools/exp_variants.sh
 #endif
 
+#ifndef FSW_FUSED_STAMPS
+#define FSW_FUSED_STAMPS 0   // 1: s_memtime stamps at the phase boundaries of k_conv_fused_unit, one record per workgroup and wavefront
+#endif                       //    (tools/exp_fused_stamps.py reads them through fsw_debug_fused_stamps)
+
 namespace fsw {
+
+#if FSW_FUSED_STAMPS
+constexpr int kFusedStampWgs = 40000;
+__device__ unsigned long long g_fused_stamps[kFusedStampWgs][4][8];
+#define FSW_FSTAMP(i)                                                                      \
+  do {                                                                                     \
+    const unsigned long long now_ = clock64();                                             \
+    if (lane_id() == 0 && blockIdx.x < kFusedStampWgs) g_fused_stamps[blockIdx.x][wave_id()][i] = now_ - fst_last; \
+    fst_last = now_;                                                                       \
+  } while (0)
+#else
+#define FSW_FSTAMP(i) do { } while (0)
+#endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -171,22 +188,12 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
   float* H = smem;                                                        // [kFusedRows][ldh]
   int* nodeS = reinterpret_cast<int*>(smem + a.tile_floats);              // [kFusedRows]
 
+#if FSW_FUSED_STAMPS
+  unsigned long long fst_last = clock64();
+#endif
   // workgroup -> (degree bin, perm range): one degree per workgroup, highest degrees first, bin 0 last
   int D, p = 0, pe = 0;
-  {
-    int b = blockIdx.x;
-    for (D = DHI; D >= DLO; --D) {
-      const int lo = a.bin_start[D], hi = a.bin_start[D + 1];
-      const int nb = (hi - lo + kFusedRows - 1) / kFusedRows;
-      if (b < nb) {
-        p = lo + b * kFusedRows;
-        pe = min(p + kFusedRows, hi);
-        break;
-      }
-      b -= nb;
-    }
-    if (D < DLO) return;
-  }
+  if (!find_degree_tile<kFusedRows>(a.bin_start, DLO, DHI, (int)blockIdx.x, D, p, pe)) return;
   const int nrows = pe - p;
   const int wv = wave_id();
   const int lane = lane_id();
@@ -201,6 +208,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
     if (a.has_mass && r < nrows)
       H[r * a.ldh] = a.out_scale * (mass_encode_f((float)D, a.mass_fn) * a.mass_scale + (a.bias ? a.bias[0] : 0.f));
   }
+  FSW_FSTAMP(0);                                           // tile found, H padding / node ids / mass column
   // phase 1: embedding rows
   // a wave = one 64-slice chunk of a group of rows.  Four or more chunks: every wave walks all 32 rows of its chunks.
   // Narrow slice blocks (one rank's share of a slice-sharded layer, dist.py): the rows are split into 4 / nchunks
@@ -223,23 +231,32 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
         break;
     }
   }
+  FSW_FSTAMP(1);                                           // phase 1: this wavefront's rows gathered, sorted, read out into H
   const int nslabs = (a.Hout + 31) / 32;
   if (nslabs <= 4) {
     // ---- Hout <= 128: one slab per wave, output tile staged through LDS so that Y is written as whole rows ----
     // Rows of Yin (= x . W2^T + b, stored by the projection kernel in perm order: this workgroup's 32 rows are one
     // contiguous run).  Wave w finishes rows 8w..8w+7; lane owns columns lane and lane+64.  Issued after phase 1
     // (registers are free again) and before the barrier: in flight while the other waves finish their rows.
+    // Branch-free (rows past the tile's end re-read its last row, columns past Hout the last column; neither is used): with a
+    // branch per load every load sat in its own basic block and waited for the one before it (s_waitcnt vmcnt(0) per block) --
+    // 10 us of a workgroup's 91 (tools/exp_fused_stamps.py)
     float yin[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = wv * 8 + (q >> 1), c = lane + 64 * (q & 1);
-      yin[q] = 0.f;
-      if ((ABL & 2) == 0 && a.Yin && row < nrows && c < a.Hout)
+    for (int q = 0; q < 16; ++q) yin[q] = 0.f;
+    if ((ABL & 2) == 0 && a.Yin) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = min(wv * 8 + (q >> 1), nrows - 1), c = min(lane + 64 * (q & 1), a.Hout - 1);
         yin[q] = a.Yin[(int64_t)(a.yin_by_node ? a.perm[p + row] : p + row) * a.ldyin + c];
+      }
     }
+    FSW_FSTAMP(2);                                         // Yin loads issued
     __syncthreads();
+    FSW_FSTAMP(3);                                         // barrier: waited for the slowest wavefront's phase 1
     f32x16 acc;
     if (wv < nslabs) slab_mma<ABL>(a, H, wv, fr, fh, acc);
+    FSW_FSTAMP(4);                                         // matrix phase
     __syncthreads();                         // every wave has finished reading H: reuse it for the output tile
     float* T = smem;                         // [kFusedRows][kLdT]
     if (wv < nslabs) {
@@ -247,6 +264,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * fh) * kLdT + wv * 32 + fr] = acc[r];
     }
     __syncthreads();
+    FSW_FSTAMP(5);                                         // barrier, accumulators into the staging tile, barrier
     float lb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) lb[h] = (!a.Yin && a.lin_bias && lane + 64 * h < a.Hout) ? a.lin_bias[lane + 64 * h] : 0.f;
@@ -266,6 +284,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
         }
       }
     }
+    FSW_FSTAMP(6);                                         // epilogue: + Yin, activation, Y rows stored
     return;
   }
 
@@ -432,3 +451,13 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   FSW_LAUNCH_CHECK();
   return 0;
 }
+
+#if FSW_FUSED_STAMPS
+// timing experiment only (not in include/fsw_hip.h): copies the per-workgroup stamp records of the last k_conv_fused_unit launch
+extern "C" int fsw_debug_fused_stamps(unsigned long long* out, int max_wgs) {
+  FSW_CHECK_HIP(hipDeviceSynchronize());
+  const int nw = max_wgs < fsw::kFusedStampWgs ? max_wgs : fsw::kFusedStampWgs;
+  FSW_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fsw::g_fused_stamps), sizeof(unsigned long long) * (size_t)nw * 4 * 8));
+  return 0;
+}
+#endif

@@ -114,20 +114,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit_bwd(const int32_t* __res
   const bool kvalid = k < S;
   const int kc = kvalid ? k : S - 1;
   int D, p = 0, pe = 0;
-  {
-    int b = blockIdx.x;
-    for (D = DHI; D >= DLO; --D) {
-      const int lo = bin_start[D], hi = bin_start[D + 1];
-      const int nb = (hi - lo + kBwdRows - 1) / kBwdRows;
-      if (b < nb) {
-        p = lo + b * kBwdRows;
-        pe = min(p + kBwdRows, hi);
-        break;
-      }
-      b -= nb;
-    }
-    if (D < DLO) return;
-  }
+  if (!find_degree_tile<kBwdRows>(bin_start, DLO, DHI, (int)blockIdx.x, D, p, pe)) return;   // fsw_common.h
   float* cS = smem + wv * (2 * DHI * kWave);
   switch (D) {
 #define X(d)                                                                                                          \
@@ -236,20 +223,7 @@ __global__ void __launch_bounds__(256) k_embed_reg_weighted_bwd(const int32_t* _
   const bool kvalid = k < S;
   const int kc = kvalid ? k : S - 1;
   int D, p = 0, pe = 0;
-  {
-    int b = blockIdx.x;
-    for (D = FSW_REG_MAX_DEG; D >= 1; --D) {
-      const int lo = bin_start[D], hi = bin_start[D + 1];
-      const int nb = (hi - lo + kBwdRows - 1) / kBwdRows;
-      if (b < nb) {
-        p = lo + b * kBwdRows;
-        pe = min(p + kBwdRows, hi);
-        break;
-      }
-      b -= nb;
-    }
-    if (D < 1) return;
-  }
+  if (!find_degree_tile<kBwdRows>(bin_start, 1, FSW_REG_MAX_DEG, (int)blockIdx.x, D, p, pe)) return;
   switch (D) {
 #define X(d)                                                                                                                 \
   case d:                                                                                                                    \

@@ -81,18 +81,7 @@ __global__ void __launch_bounds__(256) k_zero_rows(const int32_t* __restrict__ p
 // first (longest rows start earliest); bin D owns ceil(count_D / kRowsPerBlock) consecutive workgroups.
 // Returns false for the surplus workgroups of the upper-bound grid.
 __device__ __forceinline__ bool block_range(const int32_t* __restrict__ bin_start, int& D, int& p, int& pe) {
-  int b = blockIdx.x;
-  for (D = FSW_REG_MAX_DEG; D >= 1; --D) {
-    const int lo = bin_start[D], hi = bin_start[D + 1];
-    const int nb = (hi - lo + kRowsPerBlock - 1) / kRowsPerBlock;
-    if (b < nb) {
-      p = lo + b * kRowsPerBlock;
-      pe = min(p + kRowsPerBlock, hi);
-      return true;
-    }
-    b -= nb;
-  }
-  return false;
+  return find_degree_tile<kRowsPerBlock>(bin_start, 1, FSW_REG_MAX_DEG, (int)blockIdx.x, D, p, pe);   // fsw_common.h
 }
 
 // ---- unit weights ---------------------------------------------------------------------------------------

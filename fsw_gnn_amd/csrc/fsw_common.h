@@ -159,6 +159,35 @@ struct UnitCoef {
   }
 };
 
+// Workgroup index b -> (degree D, perm range [p, pe)) for the kernels that walk the degree bins DHI, DHI - 1, .. DLO in tiles of ROWS
+// rows (one degree per workgroup, the longest rows first).  ONE vector load of the bin table (lane l: bin_start[l]) and a wave-level
+// suffix sum.  The loop this replaces read bin_start[D], bin_start[D + 1] with scalar loads, bin after bin until it found the tile:
+// ~20 DEPENDENT loads, and under the kernels' col-index stream (every neighbour index is a scalar load) they miss the scalar cache --
+// the s_memtime stamps of tools/exp_fused_stamps.py put 19 us of a workgroup's 91 us before its first gather.
+template <int ROWS>
+__device__ __forceinline__ bool find_degree_tile(const int32_t* __restrict__ bin_start, int DLO, int DHI, int b, int& D, int& p, int& pe) {
+  static_assert(FSW_REG_MAX_DEG + 1 < 64, "one lane per degree bin");
+  const int lane = (int)__lane_id();
+  const int lo = bin_start[min(lane, FSW_REG_MAX_DEG + 1)];
+  const int hi = __shfl_down(lo, 1);
+  const bool mine = lane >= DLO && lane <= DHI;
+  const int nb = mine ? (hi - lo + ROWS - 1) / ROWS : 0;
+  int suf = nb;                                            // tiles of the bins >= lane
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_down(suf, off);
+    if (lane + off < 64) suf += t;
+  }
+  const int before = suf - nb;                             // tiles of the bins above this one: they come first
+  const unsigned long long hit = __ballot(mine && b >= before && b < suf);
+  if (!hit) return false;
+  D = __ffsll((long long)hit) - 1;
+  const int lo_d = __builtin_amdgcn_readlane(lo, D), hi_d = __builtin_amdgcn_readlane(hi, D);
+  p = lo_d + (b - __builtin_amdgcn_readlane(before, D)) * ROWS;
+  pe = min(p + ROWS, hi_d);
+  return true;
+}
+
 static_assert(FSW_NUM_LDS_BINS == 3 && FSW_MID_MAX_DEG == 256 && FSW_LDS_MAX_DEG == 2048, "degree_bin assumes LDS bins 512 / 1024 / 2048");
 static_assert(FSW_NUM_HUB_BINS == 4 && FSW_HUB_MAX_DEG == 32768, "degree_bin assumes hub bins 4096 / 8192 / 16384 / 32768");
 
