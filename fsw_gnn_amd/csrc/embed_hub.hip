@@ -168,7 +168,7 @@ __device__ __forceinline__ float hub_line(const int32_t* __restrict__ colrow, in
 // NW wavefronts per line, M keys per lane; NW == 1: the workgroup is four independent wavefronts on four lines (adjacent
 // slices of one row) and never synchronises -- the wave-sort classes 257..2048 (M = 8 / 16 / 32) run this way
 template <int NW, int M>
-__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, FSW_HUB_MINWAVES) k_embed_hub(
+__global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, M > 32 ? 2 : FSW_HUB_MINWAVES) k_embed_hub(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(NW == 1 ? 256 : NW * kWave, FSW_HUB_MINWAVES) 
 // 0.41 ms / 0.70 of 0.90 / 0.44 of 0.72 on the three populated classes of the RMAT-20 graph, tools/exp_hub.sh).
 // stash: 3 * NW * 64 * M floats per workgroup of the grid.
 template <int NW, int M>
-__global__ void __launch_bounds__(NW* kWave, FSW_HUB_MINWAVES) k_embed_hub_q4(
+__global__ void __launch_bounds__(NW* kWave, M > 32 ? 2 : FSW_HUB_MINWAVES) k_embed_hub_q4(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ bin_start, int bin, const float* __restrict__ Xp, int64_t ldp, int S,
     const float* __restrict__ freqs, float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, float out_scale,
@@ -1462,7 +1462,15 @@ int launch_embed_hub(const fsw_embed_args& a, int64_t rows_upper, hipStream_t st
   int rc;
   const int64_t md = a.max_degree;   // host value, <= 0 when unknown
   if ((rc = launch_hub_pair<2>(a, FSW_BIN_HUB0, rows_upper, stream))) return rc;
-  if ((md <= 0 || md > 4096) && (rc = launch_hub_pair<4>(a, FSW_BIN_HUB0 + 1, rows_upper, stream))) return rc;
+#ifndef FSW_HUB_WIDE2
+#define FSW_HUB_WIDE2 0   // 1: 4097..8192 neighbours on TWO wavefronts x 48 / 64 keys per lane (16-byte gathers + stash, one exchange level)
+#endif
+  if (FSW_HUB_WIDE2) {
+    if (md <= 0 || md > 4096) {
+      if ((rc = launch_hub<2, 48>(a, FSW_BIN_HUB0 + 1, rows_upper, stream, 0, 2 * kWave * 48))) return rc;
+      if ((rc = launch_hub<2, 64>(a, FSW_BIN_HUB0 + 1, rows_upper, stream, 2 * kWave * 48 + 1, 0x7fffffff))) return rc;
+    }
+  } else if ((md <= 0 || md > 4096) && (rc = launch_hub_pair<4>(a, FSW_BIN_HUB0 + 1, rows_upper, stream))) return rc;
   if ((md <= 0 || md > 8192) && (rc = launch_hub_pair<8>(a, FSW_BIN_HUB0 + 2, rows_upper, stream))) return rc;
   if ((md <= 0 || md > 16384) && (rc = launch_hub_pair<16>(a, FSW_BIN_HUB0 + 3, rows_upper, stream))) return rc;
   return 0;
