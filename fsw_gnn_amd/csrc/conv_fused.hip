@@ -182,18 +182,23 @@ __device__ __forceinline__ void slab_mma(const FusedArgs& a, const float* __rest
     if (g0 + u < ngroups) mma4(hp + 8 * (g0 + u), bq[u]);
 }
 
-template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0, int RPW = 1>  // ABL: timing experiments only (tools/exp_fused.py)
+// TR = rows of a workgroup's tile.  32: the output staging tile reuses H's LDS.  128 (narrow slice blocks, Hout <= 128): four
+// 32-row sub-tiles go through the matrix phase one after the other with a staging tile of their own -- a workgroup's start-up chain
+// (tile search, perm -> rowptr -> col -> first gather: three dependent round trips, ~5 us) is paid once per 128 rows instead of once
+// per 32, which at 32 slices per row is a quarter of a tile's whole life.
+template <int DLO, int DHI, int WAVES_PER_SIMD, int ABL = 0, int RPW = 1, int TR = 32>  // ABL: timing experiments only (tools/exp_fused.py)
 __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const FusedArgs a) {
+  static_assert(TR == kFusedRows || (TR == 128 && RPW == 2), "tile rows");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* H = smem;                                                        // [kFusedRows][ldh]
-  int* nodeS = reinterpret_cast<int*>(smem + a.tile_floats);              // [kFusedRows]
+  float* H = smem;                                                        // [TR][ldh]
+  int* nodeS = reinterpret_cast<int*>(smem + a.tile_floats);              // [TR]
 
 #if FSW_FUSED_STAMPS
   unsigned long long fst_last = clock64();
 #endif
   // workgroup -> (degree bin, perm range): one degree per workgroup, highest degrees first, bin 0 last
   int D, p = 0, pe = 0;
-  if (!find_degree_tile<kFusedRows>(a.bin_start, DLO, DHI, (int)blockIdx.x, D, p, pe)) return;
+  if (!find_degree_tile<TR>(a.bin_start, DLO, DHI, (int)blockIdx.x, D, p, pe)) return;
   const int nrows = pe - p;
   const int wv = wave_id();
   const int lane = lane_id();
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
   const int fr = lane & 31, fh = lane >> 5;
 
   // zero the K padding column(s) and the unused rows of H, record node ids, mass column
-  if (threadIdx.x < kFusedRows) {
+  if (threadIdx.x < TR) {
     const int r = threadIdx.x;
     for (int c = (r < nrows ? K : 0); c < a.ldh; ++c) H[r * a.ldh + c] = 0.f;
     nodeS[r] = r < nrows ? a.perm[p + r] : -1;
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
   // groups so that all four waves still gather.
   const int nchunks = (a.S + kWave - 1) / kWave;
   const int ngroups = nchunks >= 3 ? 1 : 4 / nchunks;
-  const int grows = kFusedRows / ngroups;
+  const int grows = TR / ngroups;
   for (int item = wv; item < nchunks * ngroups; item += 4) {
     const int chunk = item / ngroups, r0 = (item - chunk * ngroups) * grows;
     const int gn = min(nrows - r0, grows);
@@ -241,46 +246,52 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) k_conv_fused_unit(const F
     // Branch-free (rows past the tile's end re-read its last row, columns past Hout the last column; neither is used): with a
     // branch per load every load sat in its own basic block and waited for the one before it (s_waitcnt vmcnt(0) per block) --
     // 10 us of a workgroup's 91 (tools/exp_fused_stamps.py)
-    float yin[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) yin[q] = 0.f;
-    if ((ABL & 2) == 0 && a.Yin) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = min(wv * 8 + (q >> 1), nrows - 1), c = min(lane + 64 * (q & 1), a.Hout - 1);
-        yin[q] = a.Yin[(int64_t)(a.yin_by_node ? a.perm[p + row] : p + row) * a.ldyin + c];
-      }
-    }
-    FSW_FSTAMP(2);                                         // Yin loads issued
-    __syncthreads();
-    FSW_FSTAMP(3);                                         // barrier: waited for the slowest wavefront's phase 1
-    f32x16 acc;
-    if (wv < nslabs) slab_mma<ABL>(a, H, wv, fr, fh, acc);
-    FSW_FSTAMP(4);                                         // matrix phase
-    __syncthreads();                         // every wave has finished reading H: reuse it for the output tile
-    float* T = smem;                         // [kFusedRows][kLdT]
-    if (wv < nslabs) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * fh) * kLdT + wv * 32 + fr] = acc[r];
-    }
-    __syncthreads();
-    FSW_FSTAMP(5);                                         // barrier, accumulators into the staging tile, barrier
     float lb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) lb[h] = (!a.Yin && a.lin_bias && lane + 64 * h < a.Hout) ? a.lin_bias[lane + 64 * h] : 0.f;
+    // TR == 32: the staging tile reuses H; TR == 128: its own LDS behind the node ids (four sub-tiles read H one after the other)
+    float* T = TR == kFusedRows ? smem : reinterpret_cast<float*>(nodeS + TR);   // [32][kLdT]
+#pragma unroll 1
+    for (int r0 = 0; r0 < TR; r0 += kFusedRows) {
+      if (TR > kFusedRows && r0 >= nrows) break;           // uniform
+      const int nsub = min(nrows - r0, kFusedRows);
+      float yin[16];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = wv * 8 + rr;
-      const int node = nodeS[row];
-      if (node < 0) continue;
+      for (int q = 0; q < 16; ++q) yin[q] = 0.f;
+      if ((ABL & 2) == 0 && a.Yin) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = lane + 64 * h;
-        if (c < a.Hout) {
-          float y = T[row * kLdT + c] + lb[h] + yin[rr * 2 + h];
-          if (a.act == 1) y = fmaxf(y, 0.f);
-          else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
-          if ((ABL & 4) == 0 || y == 12345.f) a.Y[(int64_t)node * a.ldy + c] = y;
+        for (int q = 0; q < 16; ++q) {
+          const int row = r0 + min(wv * 8 + (q >> 1), nsub - 1), c = min(lane + 64 * (q & 1), a.Hout - 1);
+          yin[q] = a.Yin[(int64_t)(a.yin_by_node ? a.perm[p + row] : p + row) * a.ldyin + c];
+        }
+      }
+      FSW_FSTAMP(2);                                       // Yin loads issued
+      __syncthreads();                       // first sub-tile: phase 1 complete; later ones: the previous epilogue has read T
+      FSW_FSTAMP(3);                                       // barrier: waited for the slowest wavefront's phase 1
+      f32x16 acc;
+      if (wv < nslabs) slab_mma<ABL>(a, H + r0 * a.ldh, wv, fr, fh, acc);
+      FSW_FSTAMP(4);                                       // matrix phase
+      if (TR == kFusedRows) __syncthreads(); // every wave has finished reading H: reuse it for the output tile
+      if (wv < nslabs) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * fh) * kLdT + wv * 32 + fr] = acc[r];
+      }
+      __syncthreads();
+      FSW_FSTAMP(5);                                       // barrier, accumulators into the staging tile, barrier
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = wv * 8 + rr;
+        const int node = row < nsub ? nodeS[r0 + row] : -1;
+        if (node < 0) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = lane + 64 * h;
+          if (c < a.Hout) {
+            float y = T[row * kLdT + c] + lb[h] + yin[rr * 2 + h];
+            if (a.act == 1) y = fmaxf(y, 0.f);
+            else if (a.act == 2) y = y >= 0.f ? y : a.slope * y;
+            if ((ABL & 4) == 0 || y == 12345.f) a.Y[(int64_t)node * a.ldy + c] = y;
+          }
         }
       }
     }
@@ -400,9 +411,16 @@ extern "C" int fsw_pack_linear_f32(const float* W, int64_t ldw_in, int Hout, int
   return 0;
 }
 
+#ifndef FSW_FUSED_NARROW_ROWS
+#define FSW_FUSED_NARROW_ROWS 128   // tile rows of the narrow-block variant (32: the common tile)
+#endif
+static bool fused_wide_tile(int S, int Hout) { return FSW_FUSED_NARROW_ROWS == 128 && S <= kWave / 2 && Hout <= 128; }
+
 extern "C" size_t fsw_conv_fused_lds_bytes(int S, int has_mass) {
   const int Kp = (has_mass + S + 7) & ~7;
   const int ldh = Kp | 1;
+  if (fused_wide_tile(S, 128))   // H [128][ldh] | node ids [128] | staging tile [32][kLdT]
+    return (size_t)128 * ldh * sizeof(float) + 128 * sizeof(int) + (size_t)kFusedRows * kLdT * sizeof(float);
   return (size_t)kFusedRows * (ldh > kLdT ? ldh : kLdT) * sizeof(float) + kFusedRows * sizeof(int);
 }
 
@@ -420,7 +438,9 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   FSW_REQUIRE(Hout >= 1 && ldy >= Hout && ldw >= ((Hout + 31) / 32) * 32 && ldw % 32 == 0, "fsw_conv_fused_f32: bad output sizes");
   FSW_REQUIRE(((uintptr_t)Wq & 15) == 0, "fsw_conv_fused_f32: Wq must be 16-byte aligned");
   FSW_REQUIRE(act >= 0 && act <= 2, "fsw_conv_fused_f32: act must be 0 (none), 1 (relu) or 2 (leaky relu)");
-  const size_t lds = fsw_conv_fused_lds_bytes(e.S, e.has_mass);
+  const bool wide_tile = fused_wide_tile(e.S, Hout);
+  const size_t lds = wide_tile ? fsw_conv_fused_lds_bytes(e.S, e.has_mass)
+                               : (size_t)kFusedRows * ((((e.has_mass + e.S + 7) & ~7) | 1) > kLdT ? (((e.has_mass + e.S + 7) & ~7) | 1) : kLdT) * sizeof(float) + kFusedRows * sizeof(int);
   FSW_REQUIRE(lds <= 64 * 1024, "fsw_conv_fused_f32: embed_dim too wide for the fused tile (%zu B of LDS)", lds);
   FusedArgs a;
   a.rowptr = e.rowptr; a.col = e.col; a.perm = e.perm; a.bin_start = e.bin_start;
@@ -430,7 +450,7 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   a.Y = Y; a.ldy = ldy;
   a.Kp = (e.has_mass + e.S + 7) & ~7;
   a.ldh = a.Kp | 1;
-  a.tile_floats = kFusedRows * (a.ldh > kLdT ? a.ldh : kLdT);
+  a.tile_floats = wide_tile ? 128 * a.ldh : kFusedRows * (a.ldh > kLdT ? a.ldh : kLdT);
   // two launches: long rows first (more registers per wave), then degrees 0..16 at higher occupancy
   const int64_t nblocks = ceil_div(e.num_rows, kFusedRows) + FSW_REG_MAX_DEG + 1;
 #ifdef FSW_ABLATION
@@ -444,7 +464,10 @@ extern "C" int fsw_conv_fused_f32(const fsw_embed_args* args, const float* Wq, i
   }
   FSW_ABL_CASE(1) FSW_ABL_CASE(2) FSW_ABL_CASE(4) FSW_ABL_CASE(6) FSW_ABL_CASE(7)
 #endif
-  if (e.S <= kWave / 2)   // a narrow slice block: two rows per wavefront (fused_embed_rows)
+  if (wide_tile) {        // a narrow slice block, Hout <= 128: two rows per wavefront, 128-row tiles
+    const int64_t nb128 = ceil_div(e.num_rows, 128) + FSW_REG_MAX_DEG + 1;
+    k_conv_fused_unit<0, FSW_REG_MAX_DEG, FSW_FUSED_NARROW_WAVES, 0, 2, 128><<<(unsigned)nb128, 256, lds, stream>>>(a);
+  } else if (e.S <= kWave / 2)   // a narrow slice block: two rows per wavefront (fused_embed_rows)
     k_conv_fused_unit<0, FSW_REG_MAX_DEG, FSW_FUSED_NARROW_WAVES, 0, 2><<<(unsigned)nblocks, 256, lds, stream>>>(a);
   else
     k_conv_fused_unit<0, FSW_REG_MAX_DEG, 4><<<(unsigned)nblocks, 256, lds, stream>>>(a);

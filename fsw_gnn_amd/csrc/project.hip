@@ -601,6 +601,82 @@ __global__ void __launch_bounds__(KS <= 8 ? 768 : 512) k_project_bf3(const float
 #endif
 }
 
+// ---- narrow outputs (S <= 64, no second block: one rank's slice block of a slice-sharded layer, dist.py) ----------------------------
+// With one or two 32-column slabs the workgroup kernel above has one or two wavefronts on the matrix pipe and six helpers, one
+// workgroup per CU, and a barrier per 32 rows: 0.24 ms for 32 slices of the 1M x 128 input, which it only has to read once (0.1 ms).
+// Here every WAVEFRONT is on its own: it keeps the slab's three bf16 planes in registers, reads its 32-row tile of X straight from
+// global memory in the matrix instruction's A layout (lane (r, h), k-step s: X[row0 + r][16 s + 8 h .. + 7] = two 16-byte loads; a
+// 64-byte segment per row and k-step over the two h lanes), splits it in registers and stores C from the accumulators (two whole
+// 128-byte lines per instruction).  No LDS, no barrier; blockIdx.y = slab.
+template <int KS>
+__global__ void __launch_bounds__(256, 2) k_project_narrow(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                           const float* __restrict__ V, int S, int64_t ldv, float* __restrict__ Xp,
+                                                           int64_t ldp, int32_t* __restrict__ stats, int64_t ntiles) {
+  const int lane = lane_id();
+  const int fr = lane & 31, fh = lane >> 5;
+  const int slab = blockIdx.y;
+  const int c = slab * 32 + fr;
+  bf16x8 bw[3][KS];
+  {
+    const float* wrow = c < S ? V + (int64_t)c * ldv : nullptr;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * fh + j;
+        const float v = (wrow && k < d) ? wrow[k] : 0.f;
+        __bf16 h1, h2, h3;
+        split3(v, h1, h2, h3);
+        bw[0][s][j] = h1;
+        bw[1][s][j] = h2;
+        bw[2][s][j] = h3;
+      }
+  }
+  int nonfinite = 0;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t row0 = tile * BS_ROWS;
+    const int64_t row = min(row0 + fr, n - 1);              // rows past the end re-read the last row; their outputs are not stored
+    const float* xr = X + row * ldx + 8 * fh;
+    float4 q[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = min(16 * s, d - 16);                   // d is a multiple of 16 (launch condition): k-steps past d re-read the
+      q[s][0] = *reinterpret_cast<const float4*>(xr + k0);  // last one against zero weights
+      q[s][1] = *reinterpret_cast<const float4*>(xr + k0 + 4);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float v[8] = {q[s][0].x, q[s][0].y, q[s][0].z, q[s][0].w, q[s][1].x, q[s][1].y, q[s][1].z, q[s][1].w};
+      bf16x8 a1, a2, a3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        nonfinite |= !(fabsf(v[j]) <= 3.402823466e38f);
+        __bf16 h1, h2, h3;
+        split3(v[j], h1, h2, h3);
+        a1[j] = h1;
+        a2[j] = h2;
+        a3[j] = h3;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bw[0][s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[1][s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[2][s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bw[0][s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[1][s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[0][s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t R = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;   // C/D map of the 32x32 MFMA
+      if (R < n) Xp[R * ldp + c] = acc[r];
+    }
+  }
+  if (stats && nonfinite) atomicOr(&stats[FSW_STAT_FLAGS], FSW_FLAG_X_NONFINITE);
+}
+
 static size_t bf3_lds_bytes(int nwaves, int ks, int cbufs) {
   return sizeof(__bf16) * 2 * 3 * BS_ROWS * (16 * ks + 8) + sizeof(float) * cbufs * BS_ROWS * (nwaves * 32 + 4) + sizeof(int) * 3 * BS_ROWS;
 }
@@ -625,6 +701,18 @@ static int project_launch(const float* X, int64_t n, int d, int64_t ldx, const f
     // loads per thread -- waves without a slab only help moving X)
     const bool exact = d <= 128 && getenv("FSW_PROJECT_EXACT_FP32") && atoi(getenv("FSW_PROJECT_EXACT_FP32")) != 0;
     const int nsl1 = (int)ceil_div(S, 32), nsl2 = (int)ceil_div(H2, 32);
+#ifndef FSW_PROJECT_NARROW_MAX
+#define FSW_PROJECT_NARROW_MAX 64   // widest output (columns) of the wavefront-per-tile kernel; 0: never
+#endif
+    if (!exact && S <= FSW_PROJECT_NARROW_MAX && H2 == 0 && !x_copy && d % 16 == 0 && d <= 128 && ldp >= (int64_t)nsl1 * 32) {
+      const int64_t ntiles = ceil_div(n, BS_ROWS);
+      dim3 grid((unsigned)std::min<int64_t>(ceil_div(ntiles, 4), 512), (unsigned)nsl1);   // two workgroups of four wavefronts per CU
+      if (d <= 32) k_project_narrow<2><<<grid, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, ntiles);
+      else if (d <= 64) k_project_narrow<4><<<grid, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, ntiles);
+      else k_project_narrow<8><<<grid, 256, 0, stream>>>(X, n, d, ldx, V, S, ldv, Xp, ldp, stats, ntiles);
+      FSW_LAUNCH_CHECK();
+      return 0;
+    }
     const int nslabs = exact ? (int)ceil_div(S + H2, 32) : nsl1 + nsl2;
     // FSW_PROJECT_GROUPS=2 (experiment): d <= 128 with the slabs in two column groups of <= 6 waves, single C staging buffer, two
     // workgroups per CU.  Measured SLOWER at config 3 (0.99 against 0.67 ms: X is read twice and every tile pays a second barrier)

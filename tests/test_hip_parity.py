@@ -75,6 +75,25 @@ def test_projection_mfma_vs_float64(dev):
     L.fsw_project_f32(Xd.data_ptr(), n, d, d, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, None, 0, stats.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
     assert int(stats[0]) & _lib.FLAG_X_NONFINITE
+    # narrow outputs without the feature copy (one rank's block of a slice-sharded layer): k_project_narrow, a wavefront per 32-row
+    # tile, no LDS -- one and two slabs, row counts that are no multiple of 32, padded row strides, the non-finite flag
+    for n, d, S, ldx in ((1000, 64, 32, 64), (5003, 128, 33, 128), (70, 16, 5, 20), (4097, 128, 64, 132), (33, 32, 64, 32)):
+        X = rng.standard_normal((n, ldx)).astype(np.float32)
+        V = rng.standard_normal((S, d)).astype(np.float32)
+        Xd, Vd = t(X, dev), t(V, dev)
+        ldp = (S + 31) // 32 * 32
+        Xp = torch.full((n, ldp), float("nan"), device=dev)
+        stats = torch.zeros(8, dtype=torch.int32, device=dev)
+        rc = L.fsw_project_f32(Xd.data_ptr(), n, d, ldx, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, None, 0, stats.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = X[:, :d].astype(np.float64) @ V.astype(np.float64).T
+        assert relerr(Xp[:, :S].cpu().numpy(), ref) < 5e-7
+        assert torch.isfinite(Xp).all() and int(stats[0]) == 0
+        Xd[n - 1, d - 1] = float("nan")
+        L.fsw_project_f32(Xd.data_ptr(), n, d, ldx, Vd.data_ptr(), S, d, Xp.data_ptr(), ldp, None, 0, stats.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        assert int(stats[0]) & _lib.FLAG_X_NONFINITE
 
 
 def test_graph_build_matches_oracle_adjacency(dev):
