@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit(const int32_t* __restric
 
 // Narrow slice blocks (S <= 64): ONE 64-slice chunk exists, so instead of three waves of every workgroup leaving at once the four
 // waves split the workgroup's 32 rows; at S <= 32 two rows per wavefront step (unit_run<D, 2>).
-template <int RPW>
+// ROWS: rows per workgroup (a wavefront takes ROWS / 4 <= 64 of them): 128 for the two-rows-per-step form, so that a workgroup's
+// start-up chain (tile search, perm -> rowptr -> col -> first gather) is paid once per 128 rows (conv_fused.hip: TR)
+template <int RPW, int ROWS>
 __global__ void __launch_bounds__(256) k_embed_reg_unit_narrow(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ bin_start,
                                                                const float* __restrict__ Xp, int64_t ldp, int S,
@@ -167,8 +169,9 @@ __global__ void __launch_bounds__(256) k_embed_reg_unit_narrow(const int32_t* __
                                                                int has_mass, int mass_fn, float mass_scale) {
   const int kc = min(lane_id() % (kWave / RPW), S - 1);
   int D, p, pe;
-  if (!block_range(bin_start, D, p, pe)) return;
-  constexpr int kRowsPerWave = kRowsPerBlock / 4;
+  if (!find_degree_tile<ROWS>(bin_start, 1, FSW_REG_MAX_DEG, (int)blockIdx.x, D, p, pe)) return;
+  constexpr int kRowsPerWave = ROWS / 4;
+  static_assert(kRowsPerWave <= kWave, "a lane per row of the wavefront's share");
   p += wave_id() * kRowsPerWave;
   pe = min(pe, p + kRowsPerWave);
   if (p >= pe) return;
@@ -296,10 +299,11 @@ int launch_embed_reg(const fsw_embed_args& a, bool unit_fast, int64_t rows_upper
   if (rows_upper <= 0) return 0;
   dim3 grid((unsigned)(ceil_div(rows_upper, kRowsPerBlock) + FSW_REG_MAX_DEG), (unsigned)ceil_div(a.S, 4 * kWave));
   if (unit_fast && a.S <= kWave / 2)
-    k_embed_reg_unit_narrow<2><<<grid.x, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
-                                                          a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
+    k_embed_reg_unit_narrow<2, 128><<<(unsigned)(ceil_div(rows_upper, 128) + FSW_REG_MAX_DEG), 256, 0, stream>>>(
+        a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt, a.out, a.ldo, a.bias, a.out_scale, a.has_mass,
+        a.mass_fn, a.mass_scale);
   else if (unit_fast && a.S <= kWave)
-    k_embed_reg_unit_narrow<1><<<grid.x, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
+    k_embed_reg_unit_narrow<1, kRowsPerBlock><<<grid.x, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
                                                           a.out, a.ldo, a.bias, a.out_scale, a.has_mass, a.mass_fn, a.mass_scale);
   else if (unit_fast)
     k_embed_reg_unit<<<grid, 256, 0, stream>>>(a.rowptr, a.col, a.perm, a.bin_start, a.Xp, a.ldp, a.S, a.unit_table, a.ldt,
