@@ -328,11 +328,18 @@ __global__ void __launch_bounds__(256) k_segment_sum_rows(const float* __restric
   // entries past ptr[num_out] belong to no sender (fsw_graph_transpose sorts out-of-range columns there): never walked
   const int64_t q0 = (int64_t)blockIdx.x * kSegLen, q1 = min(q0 + kSegLen, min(nnz, (int64_t)ptr[num_out]));
   if (q0 >= q1) return;
-  // sender of entry q0: the largest j with ptr[j] <= q0 (wave-uniform binary search)
-  int64_t lo = 0, hi = num_out;
+  // sender of entry q0: the largest j with ptr[j] <= q0.  A 64-ary search -- every lane probes one of 64 evenly spaced entries of
+  // ptr, a ballot counts how many are <= q0 -- takes four rounds of one vector load at a million senders; the binary search it
+  // replaces was twenty DEPENDENT scalar loads before the workgroup's first gather (cf. find_degree_tile, fsw_common.h).
+  int64_t lo = 0, hi = num_out;                            // ptr[lo] <= q0 < ptr[hi]
   while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)ptr[mid] <= q0) lo = mid; else hi = mid;
+    const int64_t step = (hi - lo + kWave - 1) / kWave;
+    const int64_t idx = min(lo + (int64_t)(lane_id() + 1) * step, hi);
+    const bool le = idx < hi && (int64_t)ptr[idx] <= q0;   // monotone over the lanes
+    const int cnt = __popcll(__ballot(le));
+    const int64_t nlo = lo + (int64_t)cnt * step;
+    hi = min(nlo + step, hi);
+    lo = nlo;
   }
   int64_t j = lo;
   int64_t nextb = ptr[j + 1];
