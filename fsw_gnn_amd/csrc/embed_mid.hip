@@ -54,19 +54,25 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
   const bool lin = xif < 1e-30f;   // xi == 0: Delta_t = 2 w_t
   const float b = bias ? out_scale * bias[has_mass + kc] : 0.f;
   const float* xk = Xp + kc;
-  for (int p = pbeg + blockIdx.x; p < pend; p += gridDim.x) {
+  // A row's descriptors arrive ahead of it: its node id (perm) is requested before the previous row's gather, its CSR range (rowptr)
+  // before the previous row's sort -- read in place they were two dependent scalar round trips at the top of every row.
+  int p = pbeg + blockIdx.x;
+  int node = p < pend ? perm[p] : 0;
+  int start = rowptr[node], end = rowptr[node + 1];
+  for (; p < pend; p += gridDim.x) {
 #if FSW_MID_ROW_BARRIER
     if (DP >= FSW_MID_ROW_BARRIER) __builtin_amdgcn_s_barrier();   // the four wavefronts walk the unrolled network together (instruction cache)
 #endif
-    const int node = perm[p];
-    const int start = rowptr[node];
-    const int D = rowptr[node + 1] - start;   // FSW_REG_MAX_DEG < D <= DP
+    const int pn = p + (int)gridDim.x;
+    const int node_n = pn < pend ? perm[pn] : 0;
+    const int D = end - start;   // FSW_REG_MAX_DEG < D <= DP
     KeyNet<DP> net;
 #pragma unroll
     for (int t = 0; t < DP; ++t) {
       net.k[t] = __builtin_inff();
       if (t < D) net.k[t] = xk[(int64_t)col[start + t] * ldp];
     }
+    const int start_n = rowptr[node_n], end_n = rowptr[node_n + 1];
     sort_network<DP>(net);
     // D in a vector register the compiler cannot prove uniform: `r < D` with a scalar D becomes one 64-bit lane mask per wire, all
     // of them computed up front and spilled (v_writelane + 2-3 v_readlane per wire); a vector compare is one instruction
@@ -93,6 +99,9 @@ __global__ void __launch_bounds__(256) k_embed_mid_unit(const int32_t* __restric
     orow[has_mass + kc] = acc;
     if (has_mass && chunk == 0 && lane_id() == 0)
       orow[0] = out_scale * (mass_encode_m((float)D, mass_fn) * mass_scale + (bias ? bias[0] : 0.f));
+    node = node_n;
+    start = start_n;
+    end = end_n;
   }
 }
 
